@@ -1,0 +1,84 @@
+"""Pins the CPU oracle (oracle/mvs_oracle.c) to vectors captured from the imported reference.
+
+Fixtures: tests/golden/fx_*.npz made by tests/golden/gen_golden.py (runs /root/reference on CPU).
+Tolerances are fp32 summation-order noise; every stage is checked on its own so an error in one
+stage cannot hide behind another.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_conf_close, load_fixture, rel_l1
+from oracle import oracle as orc
+
+
+def _sd(weights, fx=None):
+    sd = orc.costreg_state(weights)
+    if fx is not None and "prob_gain_extra" in fx:
+        sd = dict(sd)
+        sd["prob.weight"] = sd["prob.weight"] * fx["prob_gain_extra"]
+    return sd
+
+
+@pytest.mark.parametrize("name", ["tiny", "oob"])
+def test_homo_warp_matches_reference(name):
+    fx = load_fixture(name)
+    feats, proj, dv = fx["features"][0], fx["proj_matrices"][0], fx["depth_values"][0]
+    for v in range(1, feats.shape[0]):
+        got = orc.homo_warp(feats[v], proj[v], proj[0], dv)
+        want = fx["warped"][0, v - 1]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+        assert (got != 0).any()
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob", "sharp"])
+def test_variance_matches_reference(name):
+    fx = load_fixture(name)
+    got = orc.variance_volume(fx["features"][0], fx["proj_matrices"][0], fx["depth_values"][0])
+    np.testing.assert_allclose(got, fx["variance"][0], rtol=0, atol=3e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "sharp"])
+def test_costreg_matches_reference(name, weights):
+    fx = load_fixture(name)
+    cost = orc.costreg_forward(fx["variance"][0], _sd(weights, fx))
+    scale = np.abs(fx["cost_reg"][0]).max()
+    np.testing.assert_allclose(cost, fx["cost_reg"][0], rtol=0, atol=2e-4 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "sharp", "cfg1"])
+def test_softargmin_conf_matches_reference(name):
+    fx = load_fixture(name)
+    if "prob_volume" in fx:
+        depth, conf, idx, prob = orc.softargmin_conf(fx["cost_reg"][0], fx["depth_values"][0],
+                                                     want_prob=True)
+        np.testing.assert_allclose(prob, fx["prob_volume"][0], rtol=0, atol=1e-6)
+    else:
+        depth, conf, idx = orc.softargmin_conf(fx["cost_reg"][0], fx["depth_values"][0])
+    np.testing.assert_allclose(depth, fx["depth"][0], rtol=0, atol=2e-3)  # depths ~ 450 mm
+    np.testing.assert_allclose(idx, fx["expected_index"][0], rtol=0, atol=1e-4)
+    assert_conf_close(conf, fx["photometric_confidence"][0], fx["expected_index"][0],
+                      prob=fx["prob_volume"][0] if "prob_volume" in fx else None, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob", "b2", "cfg1", "sharp"])
+def test_full_path_matches_reference(name, weights):
+    fx = load_fixture(name)
+    sd = _sd(weights, fx)
+    for b in range(fx["features"].shape[0]):
+        depth, conf = orc.depth_infer(fx["features"][b], fx["proj_matrices"][b],
+                                      fx["depth_values"][b], sd)
+        assert rel_l1(depth, fx["depth"][b]) < 1e-5  # north_star bound is 1e-3
+        assert_conf_close(conf, fx["photometric_confidence"][b], fx["expected_index"][b],
+                          prob=fx["prob_volume"][b] if "prob_volume" in fx else None, atol=5e-4)
+
+
+def test_nonfinite_coordinates_give_nan():
+    """z == 0 at the sampled point -> inf/NaN grid -> NaN output (torch CPU grid_sample)."""
+    C, h, w = 2, 4, 4
+    fea = np.ones((C, h, w), np.float32)
+    ref = np.eye(4, dtype=np.float32)
+    src = np.eye(4, dtype=np.float32)
+    src[2, 3] = -1.0  # p.z = d - 1 -> 0 at d = 1
+    out = orc.homo_warp(fea, src, ref, np.array([1.0, 2.0], np.float32))
+    assert np.isnan(out[:, 0]).all()
+    assert np.isfinite(out[:, 1]).all()
