@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- depth maps/sec of the MI355X-native MVSNet depth path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic depth-map problem (features already
+resident in HBM -> depth + confidence), i.e. reference models/mvsnet.py:145-218.  Every rank
+processes its own independent maps (reference views shard embarrassingly); the
+only collective is one RCCL all-gather of the [K,2,h,w] results at the end (inside the timed
+region).  Rank 0 prints ONE JSON line.
+
+The timed region launches the path stage by stage through the C ABI with HIP events (torch
+events on the launch stream) around every stage, so per-kernel durations -- and the roofline
+figure of the dominant kernel -- are measured live over exactly the timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from scene_3dreconstruction_mvsnet_amd import _lib, synthetic  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+
+LAYERS = [  # (name, cin, cout, level_in, level_out, kind)
+    ("conv0", 32, 8, 0, 0, "conv"), ("conv1", 8, 16, 0, 1, "conv"), ("conv2", 16, 16, 1, 1, "conv"),
+    ("conv3", 16, 32, 1, 2, "conv"), ("conv4", 32, 32, 2, 2, "conv"), ("conv5", 32, 64, 2, 3, "conv"),
+    ("conv6", 64, 64, 3, 3, "conv"), ("conv7", 64, 32, 3, 2, "deconv"), ("conv9", 32, 16, 2, 1, "deconv"),
+    ("conv11", 16, 8, 1, 0, "deconv"), ("prob", 8, 1, 0, 0, "conv"),
+]
+
+
+def stage_costs(N, D, h, w, es=4):
+    """Algorithmic bytes / FLOPs per stage per map (SURVEY.md §8 d3 definitions)."""
+    V0 = D * h * w
+    costs = {"warp_variance": dict(bytes=N * 32 * h * w * 4 + 32 * V0 * es, flops=0.0)}
+    for name, ci, co, li, lo, kind in LAYERS:
+        vin, vout = V0 >> (3 * li), V0 >> (3 * lo)
+        skip = co * vout * es if kind == "deconv" else 0
+        out_es = 4 if name == "prob" else es
+        flops = 2.0 * 27 * ci * co * (vin if kind == "deconv" else vout)
+        costs[name] = dict(bytes=ci * vin * es + co * vout * out_es + skip, flops=flops)
+    costs["softargmin"] = dict(bytes=V0 * 4 + 2 * h * w * 4, flops=0.0)
+    return costs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-call", action="store_true",
+                    help="time mvs_depth_infer (one C call per map) instead of the staged calls")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with python -m torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synthetic.CONFIGS[args.config]
+    N, D, h, w = cfg["nviews"], cfg["D"], cfg["H"] // 4, cfg["W"] // 4
+    K, Wm = args.steps, args.warmup
+    _lib.load()
+
+    # ---- synthetic problem (per-rank seed: every rank owns different ref views) -------------
+    feats_np = synthetic.random_features(N, 32, h, w, seed=rank)
+    proj_np = synthetic.cameras(N, h, w)
+    dv_np = synthetic.depth_values(D, interval_scale=cfg["interval_scale"])
+    sd = synthetic.random_costreg_state(seed=0)
+    feats = torch.from_numpy(feats_np).to(dev)
+    proj = torch.from_numpy(proj_np).to(dev)
+    dv = torch.from_numpy(dv_np).to(dev)
+    blob = _lib.pack_weights(sd).to(dev)
+    ws = _lib.alloc_workspace(N, 32, D, h, w, dev)
+    out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
+    gathered = torch.empty((world * K, 2, h, w), dtype=torch.float32, device=dev) if world > 1 else None
+
+    stage_names = ["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"]
+    n_ev = len(stage_names) + 1
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(K)]
+
+    def step_staged(k, ev=None):
+        rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
+        rec(0)
+        rt = _lib.relative_proj(proj)
+        rec(1)
+        x = _lib.warp_variance(feats, rt, dv, ws)
+        rec(2)
+        acts = {}
+        for li in range(11):
+            skip = {7: acts.get(4), 8: acts.get(2), 9: acts.get(0)}.get(li)
+            x = _lib.conv_layer(li, x, skip, blob)
+            acts[li] = x
+            rec(3 + li)
+        lib = _lib.load()
+        _lib.check(lib.mvs_softargmin_conf(x.data_ptr(), dv.data_ptr(), out[k, 0].data_ptr(),
+                                           out[k, 1].data_ptr(), D, h, w, _lib._stream(dev)))
+        rec(14)
+
+    def step_fused(k, ev=None):
+        _lib.depth_infer(feats, proj, dv, blob, ws, out[k, 0], out[k, 1])
+
+    step = step_fused if args.fused_call else step_staged
+
+    for i in range(Wm):
+        step(i % K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k, events[k])
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, out)  # the final gather (RCCL over xGMI)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    maps_per_s = world * K / elapsed
+    ms_per_step = elapsed / K * 1e3
+
+    # ---- per-stage durations from the events of the timed steps -----------------------------
+    costs = stage_costs(N, D, h, w)
+    stages = {}
+    if not args.fused_call:
+        for si, name in enumerate(stage_names):
+            ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in range(K)]))
+            ent = {"ms": round(ms, 4)}
+            c = costs.get(name)
+            if c and ms > 0:
+                ent["GBps"] = round(c["bytes"] / ms / 1e6, 1)
+                if c["flops"]:
+                    ent["TFLOPs"] = round(c["flops"] / ms / 1e9, 2)
+            stages[name] = ent
+    roofline = None
+    if stages:
+        dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
+        c, ms = costs[dom], stages[dom]["ms"]
+        t_hbm = c["bytes"] / (HBM_PEAK_GBPS * 1e9)
+        t_mfma = c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        if t_mfma > t_hbm:
+            ach = c["flops"] / ms / 1e9
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3),
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
+                        "algorithmic_bytes": c["bytes"]}
+        else:
+            ach = c["bytes"] / ms / 1e6
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": c["bytes"]}
+
+    path_bytes = sum(c["bytes"] for c in costs.values())
+    path_flops = sum(c["flops"] for c in costs.values())
+    stagewise_floor_s = sum(max(c["bytes"] / (HBM_PEAK_GBPS * 1e9),
+                                c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)) for c in costs.values())
+
+    # ---- CPU baseline (rank 0, N=1): the oracle on one full map of the same workload ---------
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        tc = time.perf_counter()
+        depth_o, conf_o = orc.depth_infer(feats_np, proj_np, dv_np, sd)
+        tc = time.perf_counter() - tc
+        cpu_baseline = {"value": round(1.0 / tc, 5), "unit": "depth maps/s", "cores": orc.num_threads(),
+                        "kind": "port",
+                        "sample": f"1 full {args.config} map (N={N}, {h}x{w}x{D}) through oracle/ "
+                                  f"(C + OpenMP restatement), {tc:.1f} s"}
+        got = out[K - 1, 0].cpu().numpy()
+        parity = float(np.abs(got - depth_o).mean() / np.abs(depth_o).mean())
+
+    if rank == 0:
+        line = {
+            "metric": "depth maps/sec at N=5 views, 640x512, D=192; achieved HBM GB/s"
+                      if args.config == "cfg2" else f"depth maps/sec ({args.config})",
+            "value": round(maps_per_s, 3), "unit": "depth maps/s", "n_gpus": world, "steps": K,
+            "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: N={N} views, {cfg['H']}x{cfg['W']} image -> "
+                                   f"{h}x{w} features, D={D}, C=32, fp32; path-only (features "
+                                   "resident in HBM -> depth+confidence)",
+                       "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
+                                                       "all-gather of results at the end",
+                       "call": "fused mvs_depth_infer" if args.fused_call else "staged C-ABI calls"},
+            "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),
+            "hbm_frac_of_peak": round(path_bytes * maps_per_s / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "path": {"algorithmic_bytes": path_bytes, "algorithmic_flops": path_flops,
+                     "stagewise_roofline_ms": round(stagewise_floor_s * 1e3, 4),
+                     "frac_of_stagewise_roofline": round(stagewise_floor_s / (elapsed / K), 4)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "stages": stages,
+            "parity_rel_l1_vs_oracle": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * mvs_abi.h -- C ABI of the MI355X-native MVSNet depth-inference path (libmvs_hip.so).
+ *
+ * Drop-in boundary: these are the entry points the reference's Python side
+ * binds (ctypes) to replace, for inference, the torch ops dispatched by
+ *   models/mvsnet.py:145-218  (cost volume -> CostRegNet -> soft-argmin / confidence)
+ *   models/module.py:96-147   (homo_warping, depth_regression)
+ * of /root/reference.  FeatureNet (models/mvsnet.py:10-30) stays on PyTorch-ROCm and hands
+ * its NCHW fp32 output to mvs_warp_variance / mvs_depth_infer.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and ints; no torch / C++ types.
+ *  - Every `dev` pointer is device memory owned by the caller (torch's allocator); the library
+ *    borrows it for the duration of the enqueue and allocates nothing on the device.
+ *  - Work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream).  No entry point synchronises the device.
+ *  - Return value: MVS_OK or an error code; mvs_last_error_string() (thread-local) explains it.
+ *    The library never aborts the process.
+ *  - Re-entrant: no mutable global state besides the thread-local error string.
+ *  - Volumes between stages use a PRIVATE channels-last layout ([D][h][w][C]); only the
+ *    documented inputs/outputs below have reference layouts.
+ */
+#ifndef MVS_ABI_H
+#define MVS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_ABI_VERSION 1
+
+typedef enum mvs_status {
+    MVS_OK = 0,
+    MVS_ERR_BAD_SHAPE = 1,   /* dims not supported (C != 32, D/h/w not multiples of 8, N < 1 ...);
+                                the reference raises a torch shape error here (mvsnet.py:69-71) */
+    MVS_ERR_BAD_DTYPE = 2,   /* storage dtype not implemented */
+    MVS_ERR_WORKSPACE = 3,   /* workspace / blob too small or misaligned */
+    MVS_ERR_HIP = 4,         /* a HIP runtime call failed (launch error ...) */
+    MVS_ERR_NULL = 5         /* required pointer is NULL */
+} mvs_status;
+
+/* storage dtype of the private volumes (accumulation is always fp32) */
+typedef enum mvs_dtype { MVS_F32 = 0, MVS_F16 = 1, MVS_BF16 = 2 } mvs_dtype;
+
+/* Number of conv layers in CostRegNet (models/mvsnet.py:35-62):
+ *   0..6 conv0..conv6, 7 conv7 (deconv), 8 conv9 (deconv), 9 conv11 (deconv), 10 prob */
+#define MVS_NUM_LAYERS 11
+
+int mvs_abi_version(void);
+
+/* Thread-local description of the last non-OK status returned on this thread. */
+const char* mvs_last_error_string(void);
+
+/* Bytes of device workspace needed by mvs_depth_infer / mvs_warp_variance / mvs_costreg_forward
+ * for a [N views, C, D, h, w] problem.  Replaces nothing in the reference (torch allocates its
+ * intermediates implicitly at models/mvsnet.py:145-180). */
+int mvs_query_workspace(int N, int C, int D, int h, int w, int dtype, size_t* bytes);
+
+/* Bytes of the packed weight blob produced by mvs_pack_weights. */
+int mvs_query_weights_blob(size_t* bytes);
+
+/* HOST function.  Folds eval-mode BatchNorm3d (eps as given; torch default 1e-5) into the conv
+ * weights and re-lays them out for the kernels.  Replaces the per-forward BN arithmetic of
+ * models/module.py:29-33 and models/mvsnet.py:47-60.
+ *   conv_weights[l]  host fp32, reference layout: Conv3d [Cout][Cin][3][3][3] for l in 0..6,10;
+ *                    ConvTranspose3d [Cin][Cout][3][3][3] for l in 7..9
+ *   bn_params[4*l+{0,1,2,3}] = gamma, beta, running_mean, running_var of layer l (l in 0..9)
+ *   prob_bias        host fp32 [1]          (cost_regularization.prob.bias)
+ *   blob_out         host buffer of mvs_query_weights_blob() bytes; copy it to the device
+ *                    and pass that device pointer as `weights_blob` below. */
+int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_params,
+                     const float* prob_bias, float eps, void* blob_out, size_t blob_bytes);
+
+/* rt_out[(v-1)*12 .. +12] = rows 0..2 of proj[v] @ inverse(proj[0]) as rot (9, row-major) then
+ * trans (3), for v = 1..N-1.   Replaces torch.inverse/matmul at models/module.py:107-109.
+ *   proj   dev fp32 [N][4][4]      rt_out dev fp32 [(N-1)][12] */
+int mvs_relative_proj(const float* proj, float* rt_out, int N, void* stream);
+
+/* Fused homography warp + variance cost volume.
+ * Replaces models/module.py:96-139 (per source view) and models/mvsnet.py:145-177.
+ *   feats         dev fp32 [N][C][h][w]   (FeatureNet outputs, view 0 = reference view)
+ *   rt            dev fp32 [(N-1)][12]    (from mvs_relative_proj)
+ *   depth_values  dev fp32 [D]
+ *   var_out       dev, private layout [D][h][w][C] in `dtype`
+ *   workspace     dev, >= mvs_query_workspace bytes (uses the feature-transpose region only) */
+int mvs_warp_variance(const float* feats, const float* rt, const float* depth_values,
+                      void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
+                      int h, int w, int dtype, void* stream);
+
+/* 3D U-Net cost regularisation.  Replaces CostRegNet.forward, models/mvsnet.py:64-73.
+ *   var           dev [D][h][w][32] in `dtype` (from mvs_warp_variance)
+ *   weights_blob  dev copy of the mvs_pack_weights blob
+ *   cost_out      dev fp32 [D][h][w]  (== cost_reg.squeeze(1) of models/mvsnet.py:192) */
+int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_out,
+                        void* workspace, size_t workspace_bytes, int D, int h, int w, int dtype,
+                        void* stream);
+
+/* One CostRegNet layer (0..10, table above) on channels-last tensors: the building block of
+ * mvs_costreg_forward, exported for per-layer parity tests and per-kernel timing in bench.py.
+ * Replaces one ConvBnReLU3D / ConvTranspose3d+BN+ReLU(+skip) / prob conv of
+ * models/mvsnet.py:36-62.
+ *   x     dev [Di][Hi][Wi][Cin]    skip  dev [Do][Ho][Wo][Cout] or NULL (layers 7..9 need it)
+ *   y     dev [Do][Ho][Wo][Cout]   (layer 10: fp32 [D][h][w]) */
+int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
+                   int Di, int Hi, int Wi, int dtype, void* stream);
+
+/* softmax over D, depth expectation and photometric confidence in one pass.
+ * Replaces models/mvsnet.py:192-193,204,214-218 and models/module.py:144-147.
+ *   cost dev fp32 [D][h][w]; depth_out, conf_out dev fp32 [h][w] */
+int mvs_softargmin_conf(const float* cost, const float* depth_values, float* depth_out,
+                        float* conf_out, int D, int h, int w, void* stream);
+
+/* mvs_relative_proj -> mvs_warp_variance -> mvs_costreg_forward -> mvs_softargmin_conf for one
+ * batch item.  Replaces models/mvsnet.py:145-218 after FeatureNet.
+ *   proj dev fp32 [N][4][4]; other arguments as above. */
+int mvs_depth_infer(const float* feats, const float* proj, const float* depth_values,
+                    const void* weights_blob, float* depth_out, float* conf_out, void* workspace,
+                    size_t workspace_bytes, int N, int C, int D, int h, int w, int dtype,
+                    void* stream);
+
+/* Stand-alone ops with reference layouts (API parity with models/module.py).
+ * mvs_homo_warp: src_fea dev fp32 [C][h][w], rt dev fp32 [12] -> out dev fp32 [C][D][h][w]
+ *   (models/module.py:96-139 for one batch item).
+ * mvs_depth_regression: p dev fp32 [D][h][w] -> depth dev fp32 [h][w] = sum_d p*depth_values
+ *   (models/module.py:144-147). */
+int mvs_homo_warp(const float* src_fea, const float* rt, const float* depth_values, float* out,
+                  int C, int D, int h, int w, void* stream);
+int mvs_depth_regression(const float* p, const float* depth_values, float* depth_out, int D,
+                         int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_ABI_H */

@@ -1,0 +1,239 @@
+"""ctypes binding of libmvs_hip.so (the C ABI declared in include/mvs_abi.h).
+
+There is no CPU fallback: if the shared library is missing or an entry point fails, a
+RuntimeError is raised.  `import torch` must happen before the library is loaded so that the
+HIP runtime torch ships (same soname, libamdhip64.so.7) is the one both sides share -- stream
+handles and device pointers are only meaningful inside one runtime instance.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported first, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
+
+MVS_F32, MVS_F16, MVS_BF16 = 0, 1, 2
+NUM_LAYERS = 11
+ABI_VERSION = 1
+
+# every symbol include/mvs_abi.h declares
+SYMBOLS = (
+    "mvs_abi_version", "mvs_last_error_string", "mvs_query_workspace", "mvs_query_weights_blob",
+    "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_costreg_forward",
+    "mvs_conv_layer", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
+)
+
+_lock = threading.Lock()
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_sz = ctypes.c_size_t
+
+
+class MvsError(RuntimeError):
+    """Non-zero status from libmvs_hip.so (decoded with mvs_last_error_string)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libmvs_hip status {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libmvs_hip.so once; raises RuntimeError if it is missing (no fallback)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or make -C scene_3dreconstruction_mvsnet_amd/csrc). "
+                "There is no CPU/PyTorch fallback for the MVSNet depth path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name in SYMBOLS:
+            if not hasattr(lib, name):
+                raise RuntimeError(f"{LIB_PATH} does not export {name}")
+        lib.mvs_abi_version.restype = _i
+        lib.mvs_last_error_string.restype = ctypes.c_char_p
+        lib.mvs_query_workspace.argtypes = [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_sz)]
+        lib.mvs_query_weights_blob.argtypes = [ctypes.POINTER(_sz)]
+        lib.mvs_pack_weights.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp,
+                                         ctypes.c_float, _vp, _sz]
+        lib.mvs_relative_proj.argtypes = [_vp, _vp, _i, _vp]
+        lib.mvs_warp_variance.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]
+        lib.mvs_costreg_forward.argtypes = [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]
+        lib.mvs_conv_layer.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+        lib.mvs_softargmin_conf.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+        lib.mvs_depth_infer.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _i, _i, _i, _i, _i, _i, _vp]
+        lib.mvs_homo_warp.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+        lib.mvs_depth_regression.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
+        for name in SYMBOLS:
+            if name not in ("mvs_last_error_string",):
+                getattr(lib, name).restype = _i
+        if lib.mvs_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libmvs_hip ABI {lib.mvs_abi_version()} != expected {ABI_VERSION}")
+        _lib = lib
+        return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise MvsError(status, load().mvs_last_error_string().decode("utf-8", "replace"))
+
+
+def query_workspace(N, C, D, h, w, dtype=MVS_F32) -> int:
+    n = _sz(0)
+    check(load().mvs_query_workspace(N, C, D, h, w, dtype, ctypes.byref(n)))
+    return int(n.value)
+
+
+def query_weights_blob() -> int:
+    n = _sz(0)
+    check(load().mvs_query_weights_blob(ctypes.byref(n)))
+    return int(n.value)
+
+
+def _stream(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MVSNet depth path "
+                           "has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+# reference parameter names, relative to `cost_regularization.` (models/mvsnet.py:35-62)
+CONV_WEIGHT_KEYS = tuple([f"conv{i}.conv.weight" for i in range(7)] +
+                         ["conv7.0.weight", "conv9.0.weight", "conv11.0.weight", "prob.weight"])
+BN_PREFIXES = tuple([f"conv{i}.bn" for i in range(7)] + ["conv7.1", "conv9.1", "conv11.1"])
+_LAYER_CH = ((32, 8), (8, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64),
+             (64, 32), (32, 16), (16, 8), (8, 1))
+
+
+def pack_weights(state: dict, eps: float = 1e-5) -> torch.Tensor:
+    """BN-fold + re-layout the CostRegNet parameters into the kernels' blob (host, uint8).
+
+    `state` maps names relative to `cost_regularization.` to CPU float32 tensors/arrays.
+    """
+    import numpy as np
+
+    lib = load()
+    keep = []
+
+    def arr(key, shape):
+        a = state[key]
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise RuntimeError(f"{key}: shape {tuple(a.shape)} != expected {tuple(shape)}")
+        keep.append(a)
+        return a.ctypes.data
+
+    convs = (_vp * NUM_LAYERS)()
+    for l, key in enumerate(CONV_WEIGHT_KEYS):
+        ci, co = _LAYER_CH[l]
+        shape = (ci, co, 3, 3, 3) if 7 <= l <= 9 else (co, ci, 3, 3, 3)
+        convs[l] = arr(key, shape)
+    bns = (_vp * 40)()
+    for l, pre in enumerate(BN_PREFIXES):
+        co = _LAYER_CH[l][1]
+        for j, suffix in enumerate(("weight", "bias", "running_mean", "running_var")):
+            bns[4 * l + j] = arr(f"{pre}.{suffix}", (co,))
+    bias = arr("prob.bias", (1,))
+    nbytes = query_weights_blob()
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    check(lib.mvs_pack_weights(convs, bns, bias, ctypes.c_float(eps), blob.data_ptr(), nbytes))
+    return blob
+
+
+def relative_proj(proj: torch.Tensor) -> torch.Tensor:
+    """proj [N,4,4] cuda -> rt [(N-1),12] cuda (models/module.py:107-109)."""
+    proj = _dev_f32(proj, "proj_matrices")
+    N = proj.shape[0]
+    rt = torch.empty((max(N - 1, 1), 12), dtype=torch.float32, device=proj.device)
+    check(load().mvs_relative_proj(proj.data_ptr(), rt.data_ptr(), N, _stream(proj.device)))
+    return rt
+
+
+def warp_variance(feats, rt, depth_values, workspace, dtype=MVS_F32):
+    """feats [N,32,h,w], rt [(N-1),12], depth_values [D] -> private volume tensor [D,h,w,32]."""
+    feats = _dev_f32(feats, "features")
+    N, C, h, w = feats.shape
+    D = depth_values.shape[0]
+    var = torch.empty((D, h, w, C), dtype=torch.float32, device=feats.device)
+    check(load().mvs_warp_variance(feats.data_ptr(), rt.data_ptr(),
+                                   _dev_f32(depth_values, "depth_values").data_ptr(),
+                                   var.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                   N, C, D, h, w, dtype, _stream(feats.device)))
+    return var
+
+
+def costreg_forward(var, blob, workspace, dtype=MVS_F32):
+    """var [D,h,w,32] (private layout) -> cost logits [D,h,w] fp32."""
+    D, h, w, _ = var.shape
+    cost = torch.empty((D, h, w), dtype=torch.float32, device=var.device)
+    check(load().mvs_costreg_forward(var.data_ptr(), blob.data_ptr(), cost.data_ptr(),
+                                     workspace.data_ptr(), workspace.numel(), D, h, w, dtype,
+                                     _stream(var.device)))
+    return cost
+
+
+def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
+    """One CostRegNet layer on channels-last tensors [D,h,w,Cin] -> [D',h',w',Cout]."""
+    ci, co = _LAYER_CH[layer]
+    Di, Hi, Wi, cin = x.shape
+    if cin != ci:
+        raise RuntimeError(f"layer {layer}: input has {cin} channels, expected {ci}")
+    if 7 <= layer <= 9:
+        oshape = (2 * Di, 2 * Hi, 2 * Wi, co)
+    elif layer in (1, 3, 5):
+        oshape = ((Di - 1) // 2 + 1, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, co)
+    else:
+        oshape = (Di, Hi, Wi, co)
+    if layer == 10:
+        oshape = oshape[:3]
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    if skip is not None and tuple(skip.shape) != tuple(oshape):
+        raise RuntimeError(f"layer {layer}: skip shape {tuple(skip.shape)} != {oshape}")
+    check(load().mvs_conv_layer(layer, x.data_ptr(), 0 if skip is None else skip.data_ptr(),
+                                y.data_ptr(), blob.data_ptr(), Di, Hi, Wi, dtype,
+                                _stream(x.device)))
+    return y
+
+
+def softargmin_conf(cost, depth_values):
+    cost = _dev_f32(cost, "cost")
+    D, h, w = cost.shape
+    depth = torch.empty((h, w), dtype=torch.float32, device=cost.device)
+    conf = torch.empty_like(depth)
+    check(load().mvs_softargmin_conf(cost.data_ptr(),
+                                     _dev_f32(depth_values, "depth_values").data_ptr(),
+                                     depth.data_ptr(), conf.data_ptr(), D, h, w,
+                                     _stream(cost.device)))
+    return depth, conf
+
+
+def depth_infer(feats, proj, depth_values, blob, workspace, depth_out, conf_out, dtype=MVS_F32):
+    """Whole path for one batch item; outputs are written into depth_out / conf_out [h,w]."""
+    N, C, h, w = feats.shape
+    D = depth_values.shape[0]
+    check(load().mvs_depth_infer(feats.data_ptr(), proj.data_ptr(), depth_values.data_ptr(),
+                                 blob.data_ptr(), depth_out.data_ptr(), conf_out.data_ptr(),
+                                 workspace.data_ptr(), workspace.numel(), N, C, D, h, w, dtype,
+                                 _stream(feats.device)))
+
+
+def alloc_workspace(N, C, D, h, w, device, dtype=MVS_F32) -> torch.Tensor:
+    nbytes = query_workspace(N, C, D, h, w, dtype)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -1,0 +1,138 @@
+// conv3d_direct.hip -- VALU direct 3x3x3 convolution / transposed convolution, channels-last.
+//
+// Baseline kernels for every CostRegNet layer (reference models/mvsnet.py:35-73 with the
+// ConvBnReLU3D block of models/module.py:26-33).  BatchNorm is already folded into the packed
+// weights (mvs_pack_weights), so each layer is  y = act(conv(x) + bias) (+ skip).
+//
+//   x    [Di][Hi][Wi][CIN]   channels-last fp32
+//   wgt  [27][CIN][COUT]     tap-major packed weights (tap = kd*9 + kh*3 + kw)
+//   y    [Do][Ho][Wo][COUT]
+//
+// One thread = one output voxel x CPT output channels.  Weight addresses are wave-uniform, so
+// the compiler streams them through the scalar cache; activations are 16-byte vector loads that
+// hit L1/L2 for the 27-fold tap reuse.  The MFMA implicit-GEMM kernels in conv3d_mfma.hip
+// replace these on the FLOP-heavy layers; these stay as the generic fallback for every shape.
+#include "mvs_internal.h"
+
+namespace mvs {
+
+template <int CIN, int COUT, int CPT, int STRIDE, bool DECONV, bool RELU, bool SKIP>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ skip,
+                                                            float* __restrict__ y, int Di, int Hi,
+                                                            int Wi, int Do, int Ho, int Wo) {
+    constexpr int GROUPS = COUT / CPT;
+    const size_t nvox = (size_t)Do * Ho * Wo;
+    const size_t vi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;  // output-channel group (wave-uniform)
+    if (vi >= nvox) return;
+    const int ow = (int)(vi % Wo), oh = (int)((vi / Wo) % Ho), od = (int)(vi / ((size_t)Wo * Ho));
+    const int co0 = g * CPT;
+    (void)GROUPS;
+
+    float acc[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) acc[j] = bias[co0 + j];
+
+    for (int kd = 0; kd < 3; ++kd) {
+        int id;
+        bool okd;
+        if (DECONV) {
+            const int t = od + 1 - kd;  // o = 2*i - 1 + k
+            id = t >> 1;
+            okd = (t >= 0) && !(t & 1) && id < Di;
+        } else {
+            id = od * STRIDE + kd - 1;
+            okd = id >= 0 && id < Di;
+        }
+        for (int kh = 0; kh < 3; ++kh) {
+            int ih;
+            bool okh;
+            if (DECONV) {
+                const int t = oh + 1 - kh;
+                ih = t >> 1;
+                okh = (t >= 0) && !(t & 1) && ih < Hi;
+            } else {
+                ih = oh * STRIDE + kh - 1;
+                okh = ih >= 0 && ih < Hi;
+            }
+            for (int kw = 0; kw < 3; ++kw) {
+                int iw;
+                bool okw;
+                if (DECONV) {
+                    const int t = ow + 1 - kw;
+                    iw = t >> 1;
+                    okw = (t >= 0) && !(t & 1) && iw < Wi;
+                } else {
+                    iw = ow * STRIDE + kw - 1;
+                    okw = iw >= 0 && iw < Wi;
+                }
+                if (!(okd && okh && okw)) continue;
+                const float* xp = x + (((size_t)id * Hi + ih) * Wi + iw) * CIN;
+                const float* wp = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * CIN * COUT + co0;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) {
+                        acc[j] = fmaf(xv.x, wp[(ci + 0) * COUT + j], acc[j]);
+                        acc[j] = fmaf(xv.y, wp[(ci + 1) * COUT + j], acc[j]);
+                        acc[j] = fmaf(xv.z, wp[(ci + 2) * COUT + j], acc[j]);
+                        acc[j] = fmaf(xv.w, wp[(ci + 3) * COUT + j], acc[j]);
+                    }
+                }
+            }
+        }
+    }
+    float* yp = y + vi * COUT + co0;
+    const float* sp = SKIP ? skip + vi * COUT + co0 : nullptr;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        float v = acc[j];
+        if (RELU) v = fmaxf(v, 0.0f);
+        if (SKIP) v += sp[j];  // skip + relu(bn(deconv(x)))   (models/mvsnet.py:69-71)
+        yp[j] = v;
+    }
+}
+
+template <int CIN, int COUT, int CPT, int STRIDE, bool DECONV, bool RELU, bool SKIP>
+static int run_direct(const void* x, const void* skip, void* y, const float* wgt, const float* bias,
+                      int Di, int Hi, int Wi, hipStream_t s) {
+    int Do, Ho, Wo;
+    if (DECONV) { Do = 2 * Di; Ho = 2 * Hi; Wo = 2 * Wi; }
+    else { Do = (Di - 1) / STRIDE + 1; Ho = (Hi - 1) / STRIDE + 1; Wo = (Wi - 1) / STRIDE + 1; }
+    const size_t nvox = (size_t)Do * Ho * Wo;
+    dim3 grid((unsigned)((nvox + 255) / 256), COUT / CPT);
+    conv3d_direct_kernel<CIN, COUT, CPT, STRIDE, DECONV, RELU, SKIP><<<grid, 256, 0, s>>>(
+        static_cast<const float*>(x), wgt, bias, static_cast<const float*>(skip),
+        static_cast<float*>(y), Di, Hi, Wi, Do, Ho, Wo);
+    return check_hip(hipGetLastError(), "conv3d_direct launch");
+}
+
+int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y, const float* wgt,
+                             const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
+    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "conv3d: dtype %d not implemented", dtype);
+    switch (layer) {
+        case 0: return run_direct<32, 8, 8, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 1: return run_direct<8, 16, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 2: return run_direct<16, 16, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 3: return run_direct<16, 32, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 4: return run_direct<32, 32, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 5: return run_direct<32, 64, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 6: return run_direct<64, 64, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 7: return run_direct<64, 32, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 8: return run_direct<32, 16, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 9: return run_direct<16, 8, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 10: return run_direct<8, 1, 1, 1, false, false, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "unknown CostRegNet layer %d", layer);
+    }
+}
+
+int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* wgt,
+                      const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
+    return launch_conv_layer_direct(layer, x, skip, y, wgt, bias, Di, Hi, Wi, dtype, s);
+}
+
+}  // namespace mvs

@@ -1,0 +1,244 @@
+// mvs_host.hip -- C-ABI entry points of libmvs_hip.so (declared in include/mvs_abi.h).
+// Host-side orchestration only: argument validation, workspace carve-up, weight packing and
+// the per-layer launch sequence of CostRegNet (reference models/mvsnet.py:64-73).
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "mvs_internal.h"
+
+namespace mvs {
+
+static thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return MVS_OK;
+    return fail(MVS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static int check_dims(int N, int C, int D, int h, int w, int dtype) {
+    if (dtype != MVS_F32 && dtype != MVS_F16 && dtype != MVS_BF16)
+        return fail(MVS_ERR_BAD_DTYPE, "unknown dtype %d", dtype);
+    if (dtype != MVS_F32)
+        return fail(MVS_ERR_BAD_DTYPE, "storage dtype %d not implemented yet (fp32 only)", dtype);
+    if (N < 1 || N > 64) return fail(MVS_ERR_BAD_SHAPE, "number of views N=%d outside [1,64]", N);
+    if (C != kC) return fail(MVS_ERR_BAD_SHAPE, "feature channels C=%d, expected %d", C, kC);
+    if (D < 8 || h < 8 || w < 8 || (D % 8) || (h % 8) || (w % 8))
+        return fail(MVS_ERR_BAD_SHAPE,
+                    "D,h,w = %d,%d,%d must be positive multiples of 8 (three stride-2 stages with "
+                    "additive skips, models/mvsnet.py:38-60,69-71)", D, h, w);
+    if ((size_t)D * h * w * kC >= ((size_t)1 << 32))
+        return fail(MVS_ERR_BAD_SHAPE, "volume of %zu elements exceeds 32-bit indexing",
+                    (size_t)D * h * w * kC);
+    return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_abi_version(void) { return MVS_ABI_VERSION; }
+
+const char* mvs_last_error_string(void) { return g_err.c_str(); }
+
+int mvs_query_workspace(int N, int C, int D, int h, int w, int dtype, size_t* bytes) {
+    if (!bytes) return fail(MVS_ERR_NULL, "bytes is NULL");
+    if (int st = check_dims(N, C, D, h, w, dtype)) return st;
+    *bytes = workspace_layout(N, C, D, h, w, dtype).total;
+    return MVS_OK;
+}
+
+int mvs_query_weights_blob(size_t* bytes) {
+    if (!bytes) return fail(MVS_ERR_NULL, "bytes is NULL");
+    *bytes = blob_layout().total_floats * sizeof(float);
+    return MVS_OK;
+}
+
+int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_params,
+                     const float* prob_bias, float eps, void* blob_out, size_t blob_bytes) {
+    if (!conv_weights || !bn_params || !prob_bias || !blob_out)
+        return fail(MVS_ERR_NULL, "mvs_pack_weights: NULL argument");
+    const BlobLayout L = blob_layout();
+    if (blob_bytes < L.total_floats * sizeof(float))
+        return fail(MVS_ERR_WORKSPACE, "weight blob needs %zu bytes, got %zu",
+                    L.total_floats * sizeof(float), blob_bytes);
+    float* blob = static_cast<float*>(blob_out);
+    std::memset(blob, 0, L.total_floats * sizeof(float));
+    for (int l = 0; l < MVS_NUM_LAYERS; ++l) {
+        const LayerSpec& S = kLayers[l];
+        const float* wsrc = conv_weights[l];
+        if (!wsrc) return fail(MVS_ERR_NULL, "conv_weights[%d] is NULL", l);
+        float* wdst = blob + L.w_off[l];
+        float* bdst = blob + L.b_off[l];
+        for (int co = 0; co < S.cout; ++co) {
+            float scale = 1.0f, shift = 0.0f;
+            if (l < 10) {
+                const float* g = bn_params[4 * l + 0];
+                const float* b = bn_params[4 * l + 1];
+                const float* m = bn_params[4 * l + 2];
+                const float* v = bn_params[4 * l + 3];
+                if (!g || !b || !m || !v) return fail(MVS_ERR_NULL, "bn_params of layer %d NULL", l);
+                // y = (x - mean) / sqrt(var + eps) * gamma + beta   (models/module.py:29-33)
+                scale = g[co] / std::sqrt(v[co] + eps);
+                shift = b[co] - m[co] * scale;
+            } else {
+                shift = prob_bias[0];
+            }
+            bdst[co] = shift;
+            for (int ci = 0; ci < S.cin; ++ci)
+                for (int t = 0; t < 27; ++t) {
+                    // Conv3d: [Cout][Cin][27]; ConvTranspose3d: [Cin][Cout][27]
+                    const size_t src = (S.kind == kConv)
+                                           ? ((size_t)co * S.cin + ci) * 27 + t
+                                           : ((size_t)ci * S.cout + co) * 27 + t;
+                    wdst[((size_t)t * S.cin + ci) * S.cout + co] = wsrc[src] * scale;
+                }
+        }
+    }
+    return MVS_OK;
+}
+
+int mvs_relative_proj(const float* proj, float* rt_out, int N, void* stream) {
+    if (!proj || !rt_out) return fail(MVS_ERR_NULL, "mvs_relative_proj: NULL argument");
+    if (N < 1 || N > 64) return fail(MVS_ERR_BAD_SHAPE, "N=%d outside [1,64]", N);
+    if (N == 1) return MVS_OK;
+    return launch_relative_proj(proj, rt_out, N, static_cast<hipStream_t>(stream));
+}
+
+int mvs_warp_variance(const float* feats, const float* rt, const float* depth_values,
+                      void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
+                      int h, int w, int dtype, void* stream) {
+    if (!feats || !depth_values || !var_out || !workspace || (N > 1 && !rt))
+        return fail(MVS_ERR_NULL, "mvs_warp_variance: NULL argument");
+    if (int st = check_dims(N, C, D, h, w, dtype)) return st;
+    const Workspace W = workspace_layout(N, C, D, h, w, dtype);
+    if (workspace_bytes < W.rt)  // only the transposed-feature region is needed here
+        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", W.rt, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
+    if (int st = launch_nchw_to_nhwc(feats, feats_t, N, C, h, w, s)) return st;
+    return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
+}
+
+int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_out,
+                        void* workspace, size_t workspace_bytes, int D, int h, int w, int dtype,
+                        void* stream) {
+    if (!var || !weights_blob || !cost_out || !workspace)
+        return fail(MVS_ERR_NULL, "mvs_costreg_forward: NULL argument");
+    if (int st = check_dims(1, kC, D, h, w, dtype)) return st;
+    // The activation regions do not depend on N; use N=1 offsets relative to the act[] base so
+    // that any workspace sized by mvs_query_workspace(N>=1,...) is large enough.
+    const Workspace W = workspace_layout(1, kC, D, h, w, dtype);
+    if (workspace_bytes < W.total)
+        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", W.total, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    const float* blob = static_cast<const float*>(weights_blob);
+    const BlobLayout L = blob_layout();
+    auto act = [&](int l) { return static_cast<void*>(ws + W.act[l]); };
+    auto run = [&](int l, const void* x, const void* skip, void* y) {
+        const int lv = kLayers[l].level_in;
+        return launch_conv_layer(l, x, skip, y, blob + L.w_off[l], blob + L.b_off[l], D >> lv,
+                                 h >> lv, w >> lv, dtype, s);
+    };
+    // models/mvsnet.py:64-73
+    int st;
+    if ((st = run(0, var, nullptr, act(0)))) return st;        // conv0
+    if ((st = run(1, act(0), nullptr, act(1)))) return st;     // conv1 (s2)
+    if ((st = run(2, act(1), nullptr, act(2)))) return st;     // conv2
+    if ((st = run(3, act(2), nullptr, act(3)))) return st;     // conv3 (s2)
+    if ((st = run(4, act(3), nullptr, act(4)))) return st;     // conv4
+    if ((st = run(5, act(4), nullptr, act(5)))) return st;     // conv5 (s2)
+    if ((st = run(6, act(5), nullptr, act(6)))) return st;     // conv6
+    if ((st = run(7, act(6), act(4), act(7)))) return st;      // conv4 + conv7(x)
+    if ((st = run(8, act(7), act(2), act(8)))) return st;      // conv2 + conv9(x)
+    if ((st = run(9, act(8), act(0), act(9)))) return st;      // conv0 + conv11(x)
+    return run(10, act(9), nullptr, cost_out);                 // prob
+}
+
+int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
+                   int Di, int Hi, int Wi, int dtype, void* stream) {
+    if (!x || !y || !weights_blob) return fail(MVS_ERR_NULL, "mvs_conv_layer: NULL argument");
+    if (layer < 0 || layer >= MVS_NUM_LAYERS) return fail(MVS_ERR_BAD_SHAPE, "layer %d outside [0,%d)", layer, MVS_NUM_LAYERS);
+    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "storage dtype %d not implemented yet (fp32 only)", dtype);
+    const LayerSpec& S = kLayers[layer];
+    if (S.kind == kDeconv && !skip) return fail(MVS_ERR_NULL, "layer %d needs its skip tensor", layer);
+    if (Di < 1 || Hi < 1 || Wi < 1 || (S.stride == 2 && S.kind == kConv && ((Di | Hi | Wi) & 1)))
+        return fail(MVS_ERR_BAD_SHAPE, "layer %d: input dims %d,%d,%d unsupported", layer, Di, Hi, Wi);
+    const BlobLayout L = blob_layout();
+    const float* blob = static_cast<const float*>(weights_blob);
+    return launch_conv_layer(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer], Di, Hi,
+                             Wi, dtype, static_cast<hipStream_t>(stream));
+}
+
+int mvs_softargmin_conf(const float* cost, const float* depth_values, float* depth_out,
+                        float* conf_out, int D, int h, int w, void* stream) {
+    if (!cost || !depth_values || !depth_out || !conf_out)
+        return fail(MVS_ERR_NULL, "mvs_softargmin_conf: NULL argument");
+    if (D < 1 || h < 1 || w < 1) return fail(MVS_ERR_BAD_SHAPE, "D,h,w = %d,%d,%d", D, h, w);
+    return launch_softargmin(cost, depth_values, depth_out, conf_out, D, h, w,
+                             static_cast<hipStream_t>(stream));
+}
+
+int mvs_depth_infer(const float* feats, const float* proj, const float* depth_values,
+                    const void* weights_blob, float* depth_out, float* conf_out, void* workspace,
+                    size_t workspace_bytes, int N, int C, int D, int h, int w, int dtype,
+                    void* stream) {
+    if (!feats || !proj || !depth_values || !weights_blob || !depth_out || !conf_out || !workspace)
+        return fail(MVS_ERR_NULL, "mvs_depth_infer: NULL argument");
+    if (int st = check_dims(N, C, D, h, w, dtype)) return st;
+    const Workspace W = workspace_layout(N, C, D, h, w, dtype);
+    if (workspace_bytes < W.total)
+        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", W.total, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    float* rt = reinterpret_cast<float*>(ws + W.rt);
+    void* var = ws + W.var;
+    float* cost = reinterpret_cast<float*>(ws + W.cost);
+    int st;
+    if ((st = mvs_relative_proj(proj, rt, N, stream))) return st;
+    if ((st = mvs_warp_variance(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
+                                h, w, dtype, stream)))
+        return st;
+    // CostRegNet activations live behind the variance volume; hand it the sub-workspace that
+    // starts at act[0] laid out as for N = 1 (same relative offsets).
+    const Workspace W1 = workspace_layout(1, C, D, h, w, dtype);
+    char* sub = ws + (W.act[0] - W1.act[0]);
+    if ((st = mvs_costreg_forward(var, weights_blob, cost, sub,
+                                  workspace_bytes - (size_t)(sub - ws), D, h, w, dtype, stream)))
+        return st;
+    return mvs_softargmin_conf(cost, depth_values, depth_out, conf_out, D, h, w, stream);
+}
+
+int mvs_homo_warp(const float* src_fea, const float* rt, const float* depth_values, float* out,
+                  int C, int D, int h, int w, void* stream) {
+    if (!src_fea || !rt || !depth_values || !out) return fail(MVS_ERR_NULL, "mvs_homo_warp: NULL argument");
+    if (C < 1 || D < 1 || h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "C,D,h,w = %d,%d,%d,%d", C, D, h, w);
+    return launch_homo_warp(src_fea, rt, depth_values, out, C, D, h, w, static_cast<hipStream_t>(stream));
+}
+
+int mvs_depth_regression(const float* p, const float* depth_values, float* depth_out, int D,
+                         int h, int w, void* stream) {
+    if (!p || !depth_values || !depth_out) return fail(MVS_ERR_NULL, "mvs_depth_regression: NULL argument");
+    if (D < 1 || h < 1 || w < 1) return fail(MVS_ERR_BAD_SHAPE, "D,h,w = %d,%d,%d", D, h, w);
+    return launch_depth_regression(p, depth_values, depth_out, D, h, w, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// mvs_internal.h -- shared host-side definitions of libmvs_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "mvs_abi.h"
+
+namespace mvs {
+
+constexpr int kC = 32;  // feature channels (FeatureNet output, models/mvsnet.py:24)
+
+// CostRegNet layer table (models/mvsnet.py:35-62).
+enum LayerKind { kConv = 0, kDeconv = 1 };
+struct LayerSpec {
+    int cin, cout, stride, kind;
+    int level_in, level_out;  // resolution level: voxel dims = (D,h,w) >> level
+};
+constexpr LayerSpec kLayers[MVS_NUM_LAYERS] = {
+    {32, 8, 1, kConv, 0, 0},     // 0 conv0
+    {8, 16, 2, kConv, 0, 1},     // 1 conv1
+    {16, 16, 1, kConv, 1, 1},    // 2 conv2
+    {16, 32, 2, kConv, 1, 2},    // 3 conv3
+    {32, 32, 1, kConv, 2, 2},    // 4 conv4
+    {32, 64, 2, kConv, 2, 3},    // 5 conv5
+    {64, 64, 1, kConv, 3, 3},    // 6 conv6
+    {64, 32, 2, kDeconv, 3, 2},  // 7 conv7  (+conv4)
+    {32, 16, 2, kDeconv, 2, 1},  // 8 conv9  (+conv2)
+    {16, 8, 2, kDeconv, 1, 0},   // 9 conv11 (+conv0)
+    {8, 1, 1, kConv, 0, 0},      // 10 prob (bias, no BN / ReLU)
+};
+
+// Packed weight blob: for every layer l, fp32 weights [27 taps][cin][cout] with BN folded in,
+// followed by fp32 bias[cout]; each section starts 256-byte aligned.  Tap index = kd*9+kh*3+kw
+// of the reference kernel (for deconv layers: the k of  o = 2*i - 1 + k).
+struct BlobLayout {
+    size_t w_off[MVS_NUM_LAYERS];  // in floats
+    size_t b_off[MVS_NUM_LAYERS];  // in floats
+    size_t total_floats;
+};
+inline BlobLayout blob_layout() {
+    BlobLayout L{};
+    size_t off = 0;
+    for (int l = 0; l < MVS_NUM_LAYERS; ++l) {
+        L.w_off[l] = off;
+        off += (size_t)27 * kLayers[l].cin * kLayers[l].cout;
+        off = (off + 63) & ~(size_t)63;
+        L.b_off[l] = off;
+        off += (size_t)kLayers[l].cout;
+        off = (off + 63) & ~(size_t)63;
+    }
+    L.total_floats = off;
+    return L;
+}
+
+inline size_t dtype_size(int dtype) { return dtype == MVS_F32 ? 4 : 2; }
+
+// Device workspace carve-up (byte offsets, 256-byte aligned).
+struct Workspace {
+    size_t feats_t;  // [N][h][w][C] fp32 channels-last copy of the features
+    size_t rt;       // [(N-1)][12] fp32
+    size_t var;      // [D][h][w][32]
+    size_t act[10];  // outputs of layers 0..9 (channels-last, storage dtype)
+    size_t cost;     // [D][h][w] fp32
+    size_t total;
+};
+inline Workspace workspace_layout(int N, int C, int D, int h, int w, int dtype) {
+    Workspace W{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t es = dtype_size(dtype);
+    W.feats_t = take((size_t)N * C * h * w * 4);
+    W.rt = take((size_t)(N > 1 ? N - 1 : 1) * 12 * 4);
+    W.var = take((size_t)D * h * w * kC * es);
+    for (int l = 0; l < 10; ++l) {
+        const int lv = kLayers[l].level_out;
+        W.act[l] = take((size_t)(D >> lv) * (h >> lv) * (w >> lv) * kLayers[l].cout * es);
+    }
+    W.cost = take((size_t)D * h * w * 4);
+    W.total = off;
+    return W;
+}
+
+// thread-local error text
+int fail(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// kernel launchers (implemented in the .hip files); all enqueue on `s` and return a status
+int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int h, int w, hipStream_t s);
+int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s);
+int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
+                         int D, int h, int w, int dtype, hipStream_t s);
+int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,
+                     int h, int w, hipStream_t s);
+int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* wgt,
+                      const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
+int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
+                      int w, hipStream_t s);
+int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,
+                            hipStream_t s);
+
+}  // namespace mvs

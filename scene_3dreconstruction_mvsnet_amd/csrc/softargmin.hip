@@ -1,0 +1,94 @@
+// softargmin.hip -- softmax over depth, depth expectation and photometric confidence (gfx950).
+//
+// Replaces, in one pass over the cost logits and without materialising the probability volume:
+//   models/mvsnet.py:192-193  squeeze + F.softmax(dim=1)
+//   models/module.py:144-147  depth_regression  (depth = sum_d p_d * depth_values_d)
+//   models/mvsnet.py:214-218  sum4 = 4*avg_pool3d(pad(p,(1,2))), idx = trunc(sum_d p_d*d),
+//                             confidence = sum4[idx] = p[idx-1]+p[idx]+p[idx+1]+p[idx+2]
+//
+// cost is [D][h][w] fp32: consecutive lanes = consecutive pixels, so every depth row is read
+// fully coalesced.  A block owns 64 pixels; its 4 waves split D into 4 slices, each doing an
+// online softmax (running max / sum / weighted sums), merged through LDS.  HBM-bound:
+// algorithmic bytes = D*h*w*4 + 2*h*w*4.
+#include "mvs_internal.h"
+
+namespace mvs {
+
+__global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __restrict__ cost,
+                                                              const float* __restrict__ dv,
+                                                              float* __restrict__ depth,
+                                                              float* __restrict__ conf, int D,
+                                                              int hw) {
+    __shared__ float s_m[4][64], s_s[4][64], s_d[4][64], s_i[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool active = p < hw;
+    const int per = (D + 3) / 4;
+    const int d0 = slice * per, d1 = min(d0 + per, D);
+    float m = -INFINITY, s = 0.0f, sd = 0.0f, si = 0.0f;
+    if (active) {
+        for (int d = d0; d < d1; ++d) {
+            const float c = cost[(size_t)d * hw + p];
+            if (c > m) {
+                const float r = expf(m - c);  // exp(-inf) = 0 on the first element
+                s *= r; sd *= r; si *= r;
+                m = c;
+            }
+            const float e = expf(c - m);
+            s += e;
+            sd = fmaf(e, dv[d], sd);
+            si = fmaf(e, (float)d, si);
+        }
+    }
+    s_m[slice][lane] = m; s_s[slice][lane] = s; s_d[slice][lane] = sd; s_i[slice][lane] = si;
+    __syncthreads();
+    if (slice != 0 || !active) return;
+    float M = fmaxf(fmaxf(s_m[0][lane], s_m[1][lane]), fmaxf(s_m[2][lane], s_m[3][lane]));
+    float S = 0.0f, SD = 0.0f, SI = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r = (s_m[k][lane] == -INFINITY) ? 0.0f : expf(s_m[k][lane] - M);
+        S = fmaf(s_s[k][lane], r, S);
+        SD = fmaf(s_d[k][lane], r, SD);
+        SI = fmaf(s_i[k][lane], r, SI);
+    }
+    const float inv = 1.0f / S;
+    depth[p] = SD * inv;
+    int idx = (int)(SI * inv);  // .long() truncation (values are >= 0)
+    idx = min(max(idx, 0), D - 1);
+    float c4 = 0.0f;
+#pragma unroll
+    for (int k = -1; k <= 2; ++k) {
+        const int j = idx + k;
+        if (j >= 0 && j < D) c4 += expf(cost[(size_t)j * hw + p] - M);
+    }
+    conf[p] = c4 * inv;
+}
+
+int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
+                      int w, hipStream_t s) {
+    const int hw = h * w;
+    softargmin_conf_kernel<<<(hw + 63) / 64, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+    return check_hip(hipGetLastError(), "softargmin launch");
+}
+
+// depth = sum_d p[d] * depth_values[d]        (models/module.py:144-147)
+__global__ __launch_bounds__(256) void depth_regression_kernel(const float* __restrict__ p,
+                                                               const float* __restrict__ dv,
+                                                               float* __restrict__ depth, int D,
+                                                               int hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) acc = fmaf(p[(size_t)d * hw + i], dv[d], acc);
+    depth[i] = acc;
+}
+
+int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,
+                            hipStream_t s) {
+    const int hw = h * w;
+    depth_regression_kernel<<<(hw + 255) / 256, 256, 0, s>>>(p, dv, depth, D, hw);
+    return check_hip(hipGetLastError(), "depth_regression launch");
+}
+
+}  // namespace mvs

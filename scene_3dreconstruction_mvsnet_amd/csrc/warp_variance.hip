@@ -1,0 +1,259 @@
+// warp_variance.hip -- homography warp + variance cost volume for gfx950 (MI355X).
+//
+// Replaces, fused into one pass and never materialising the sampling grid or the per-view
+// warped volumes:
+//   models/module.py:96-139   homo_warping (per source view)
+//   models/mvsnet.py:145-177  ref-volume repeat, sum / sum-of-squares accumulation, variance
+//
+// Data layout.  Features arrive NCHW fp32 from FeatureNet; nchw_to_nhwc_kernel re-lays them
+// channels-last ([N][h][w][32]) so that one bilinear tap of one view is ONE 128-byte line.  The
+// variance volume is written channels-last ([D][h][w][32]): 8 lanes cover one voxel (4 channels
+// = 16 B each), so a wave64 store instruction writes 8 voxels x 128 B = 1 KiB contiguous.
+//
+// HBM-bound: algorithmic bytes per map = N*32*h*w*4 (features) + 32*D*h*w*es (volume write).
+#include "mvs_internal.h"
+
+namespace mvs {
+
+// ---------------------------------------------------------------------------------------------
+// [N][C=32][h][w] -> [N][h][w][32]; one block transposes 32 channels x 64 pixels through LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
+                                                           float* __restrict__ out, int hw) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const float* src = in + (size_t)n * 32 * hw;
+    float* dst = out + (size_t)n * 32 * hw;
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const int p = p0 + tx;
+        tile[c][tx] = (p < hw) ? src[(size_t)c * hw + p] : 0.0f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, pr = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int pp = pr; pp < 64; pp += 8) {
+        const int p = p0 + pp;
+        if (p < hw) dst[(size_t)p * 32 + c] = tile[c][pp];
+    }
+}
+
+int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int h, int w, hipStream_t s) {
+    (void)C;
+    const int hw = h * w;
+    dim3 grid((hw + 63) / 64, N);
+    nchw_to_nhwc_kernel<<<grid, 256, 0, s>>>(in, out, hw);
+    return check_hip(hipGetLastError(), "nchw_to_nhwc launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// rt[v-1] = rows 0..2 of proj[v] @ inverse(proj[0])      (models/module.py:107-109)
+// One thread per source view; Gauss-Jordan with partial pivoting in fp64, rounded to fp32.
+// ---------------------------------------------------------------------------------------------
+__global__ void relative_proj_kernel(const float* __restrict__ proj, float* __restrict__ rt, int N) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (v >= N) return;
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = (double)proj[i * 4 + j];
+            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        double best = fabs(a[col][col]);
+        for (int r = col + 1; r < 4; ++r)
+            if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+        if (piv != col)
+            for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+        const double inv = 1.0 / a[col][col];  // singular ref_proj -> inf/NaN, as torch.inverse
+        for (int j = 0; j < 8; ++j) a[col][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
+        }
+    }
+    const float* ps = proj + (size_t)v * 16;
+    float* o = rt + (size_t)(v - 1) * 12;
+    for (int i = 0; i < 3; ++i) {
+        double row[4];
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += (double)ps[i * 4 + k] * a[k][4 + j];
+            row[j] = acc;
+        }
+        o[i * 3 + 0] = (float)row[0];
+        o[i * 3 + 1] = (float)row[1];
+        o[i * 3 + 2] = (float)row[2];
+        o[9 + i] = (float)row[3];
+    }
+}
+
+int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
+    relative_proj_kernel<<<1, 64, 0, s>>>(proj, rt, N);
+    return check_hip(hipGetLastError(), "relative_proj launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampling coordinate of reference pixel (x,y) at depth d in a source view.
+//   p = rot*(x,y,1)*d + trans ; px = p.x/p.z ; normalise by (W-1)/2 then grid_sample's
+//   align_corners=False un-normalisation  =>  ix = px*W/(W-1) - 0.5   (module.py:125-136)
+// ---------------------------------------------------------------------------------------------
+struct Tap {
+    int off;        // element offset of the (y0,x0) tap in an [h][w][...] map, in pixels
+    float w00, w01, w10, w11;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 when out of bounds
+    bool nan;       // non-finite coordinate -> NaN output (torch CPU grid_sample)
+};
+
+__device__ __forceinline__ Tap make_tap(float qx, float qy, float qz, float tx, float ty, float tz,
+                                        float d, float sx, float sy, int h, int w) {
+    const float X = fmaf(qx, d, tx), Y = fmaf(qy, d, ty), Z = fmaf(qz, d, tz);
+    const float ix = (X / Z) * sx - 0.5f;
+    const float iy = (Y / Z) * sy - 0.5f;
+    Tap t;
+    t.nan = !(fabsf(ix) <= 3.0e38f) || !(fabsf(iy) <= 3.0e38f);
+    const float cx = fminf(fmaxf(ix, -2.0f), (float)w + 1.0f);  // clamp keeps int casts defined;
+    const float cy = fminf(fmaxf(iy, -2.0f), (float)h + 1.0f);  // clamped taps are out of bounds
+    const float fx0 = floorf(cx), fy0 = floorf(cy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float ax = cx - fx0, ay = cy - fy0;
+    const bool in = (cx == ix) && (cy == iy);
+    const bool x0ok = in && x0 >= 0 && x0 < w, x1ok = in && x0 + 1 >= 0 && x0 + 1 < w;
+    const bool y0ok = y0 >= 0 && y0 < h, y1ok = y0 + 1 >= 0 && y0 + 1 < h;
+    t.w00 = (x0ok && y0ok) ? (1.0f - ax) * (1.0f - ay) : 0.0f;
+    t.w01 = (x1ok && y0ok) ? ax * (1.0f - ay) : 0.0f;
+    t.w10 = (x0ok && y1ok) ? (1.0f - ax) * ay : 0.0f;
+    t.w11 = (x1ok && y1ok) ? ax * ay : 0.0f;
+    // clamp the base so that all four addresses stay inside the map; weights are already zero
+    // for the taps that were moved
+    const int xb = min(max(x0, 0), w - 2), yb = min(max(y0, 0), h - 2);
+    if (xb != x0 || yb != y0) {
+        // re-associate the weights with the clamped 2x2 block
+        const float a00 = t.w00, a01 = t.w01, a10 = t.w10, a11 = t.w11;
+        float b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
+        auto put = [&](int yy, int xx, float wv) {
+            if (wv == 0.0f) return;
+            const int ry = yy - yb, rx = xx - xb;  // in {0,1} whenever wv != 0
+            if (ry == 0 && rx == 0) b00 = wv;
+            else if (ry == 0 && rx == 1) b01 = wv;
+            else if (ry == 1 && rx == 0) b10 = wv;
+            else b11 = wv;
+        };
+        put(y0, x0, a00); put(y0, x0 + 1, a01); put(y0 + 1, x0, a10); put(y0 + 1, x0 + 1, a11);
+        t.w00 = b00; t.w01 = b01; t.w10 = b10; t.w11 = b11;
+    }
+    t.off = yb * w + xb;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused warp + variance.  Block = 256 threads = 32 pixels (along x) x 8 channel-chunks; each
+// block walks a slab of DS depths so consecutive depths re-use the same source lines from L1/L2
+// (the epipolar shift per depth step is a fraction of a pixel).
+//   feats_t [N][h][w][32], rt [(N-1)][12], dv [D] -> var [D][h][w][32]
+// ---------------------------------------------------------------------------------------------
+constexpr int kWarpDepthSlab = 16;
+
+__global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restrict__ feats_t,
+                                                            const float* __restrict__ rt,
+                                                            const float* __restrict__ dv,
+                                                            float* __restrict__ var, int N, int D,
+                                                            int h, int w) {
+    const int q = threadIdx.x & 7;          // channel chunk: channels 4q..4q+3
+    const int px = threadIdx.x >> 3;        // 0..31
+    const int xblocks = (w + 31) / 32;
+    const int y = blockIdx.x / xblocks;
+    const int x = (blockIdx.x % xblocks) * 32 + px;
+    const int d0 = blockIdx.y * kWarpDepthSlab;
+    if (x >= w) return;
+    const size_t hw = (size_t)h * w;
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float4 ref = *reinterpret_cast<const float4*>(feats_t + ((size_t)y * w + x) * 32 + 4 * q);
+    const float fx = (float)x, fy = (float)y;
+    const float inv_n = 1.0f / (float)N;
+    const int d1 = min(d0 + kWarpDepthSlab, D);
+    for (int d = d0; d < d1; ++d) {
+        const float depth = dv[d];
+        float4 S = ref;
+        float4 Q = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+        bool any_nan = false;
+        for (int v = 1; v < N; ++v) {
+            const float* r = rt + (size_t)(v - 1) * 12;
+            const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+            const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+            const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+            const Tap t = make_tap(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w);
+            any_nan |= t.nan;
+            const float* f = feats_t + (size_t)v * hw * 32 + (size_t)t.off * 32 + 4 * q;
+            const float4 a = *reinterpret_cast<const float4*>(f);
+            const float4 b = *reinterpret_cast<const float4*>(f + 32);
+            const float4 c = *reinterpret_cast<const float4*>(f + (size_t)w * 32);
+            const float4 e = *reinterpret_cast<const float4*>(f + (size_t)w * 32 + 32);
+            float4 wv;
+            wv.x = fmaf(a.x, t.w00, fmaf(b.x, t.w01, fmaf(c.x, t.w10, e.x * t.w11)));
+            wv.y = fmaf(a.y, t.w00, fmaf(b.y, t.w01, fmaf(c.y, t.w10, e.y * t.w11)));
+            wv.z = fmaf(a.z, t.w00, fmaf(b.z, t.w01, fmaf(c.z, t.w10, e.z * t.w11)));
+            wv.w = fmaf(a.w, t.w00, fmaf(b.w, t.w01, fmaf(c.w, t.w10, e.w * t.w11)));
+            S.x += wv.x; S.y += wv.y; S.z += wv.z; S.w += wv.w;
+            Q.x = fmaf(wv.x, wv.x, Q.x); Q.y = fmaf(wv.y, wv.y, Q.y);
+            Q.z = fmaf(wv.z, wv.z, Q.z); Q.w = fmaf(wv.w, wv.w, Q.w);
+        }
+        // var = Q/N - (S/N)^2        (models/mvsnet.py:177)
+        float4 o;
+        float m;
+        m = S.x * inv_n; o.x = fmaf(-m, m, Q.x * inv_n);
+        m = S.y * inv_n; o.y = fmaf(-m, m, Q.y * inv_n);
+        m = S.z * inv_n; o.z = fmaf(-m, m, Q.z * inv_n);
+        m = S.w * inv_n; o.w = fmaf(-m, m, Q.w * inv_n);
+        if (any_nan) o = make_float4(NAN, NAN, NAN, NAN);
+        *reinterpret_cast<float4*>(var + (((size_t)d * h + y) * w + x) * 32 + 4 * q) = o;
+    }
+}
+
+int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
+                         int D, int h, int w, int dtype, hipStream_t s) {
+    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "warp_variance: dtype %d not implemented", dtype);
+    if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
+    dim3 grid(((w + 31) / 32) * h, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
+    warp_variance_kernel<<<grid, 256, 0, s>>>(feats_t, rt, dv, static_cast<float*>(var), N, D, h, w);
+    return check_hip(hipGetLastError(), "warp_variance launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone homo_warping with reference layouts: fea [C][h][w] -> out [C][D][h][w]
+// (models/module.py:96-139).  Thread = one (d,y,x); loops over channels (coalesced along x).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void homo_warp_kernel(const float* __restrict__ fea,
+                                                        const float* __restrict__ rt,
+                                                        const float* __restrict__ dv,
+                                                        float* __restrict__ out, int C, int D, int h,
+                                                        int w) {
+    const size_t hw = (size_t)h * w;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)D * hw) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h), d = (int)(i / hw);
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)x, fy = (float)y;
+    const float qx = fmaf(rt[0], fx, fmaf(rt[1], fy, rt[2]));
+    const float qy = fmaf(rt[3], fx, fmaf(rt[4], fy, rt[5]));
+    const float qz = fmaf(rt[6], fx, fmaf(rt[7], fy, rt[8]));
+    const Tap t = make_tap(qx, qy, qz, rt[9], rt[10], rt[11], dv[d], sx, sy, h, w);
+    for (int c = 0; c < C; ++c) {
+        const float* f = fea + (size_t)c * hw + t.off;
+        float v = fmaf(f[0], t.w00, fmaf(f[1], t.w01, fmaf(f[w], t.w10, f[w + 1] * t.w11)));
+        if (t.nan) v = NAN;
+        out[(size_t)c * D * hw + i] = v;
+    }
+}
+
+int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,
+                     int h, int w, hipStream_t s) {
+    const size_t n = (size_t)D * h * w;
+    homo_warp_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(fea, rt, dv, out, C, D, h, w);
+    return check_hip(hipGetLastError(), "homo_warp launch");
+}
+
+}  // namespace mvs

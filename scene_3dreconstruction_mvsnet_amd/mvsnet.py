@@ -1,0 +1,165 @@
+"""Drop-in `MVSNet` for the reference's models/mvsnet.py (inference path, MI355X-native).
+
+`MVSNet(refine, debug).forward(imgs, proj_matrices, depth_values)` keeps the reference signature
+and return dict (reference models/mvsnet.py:91-239); parameter/buffer names equal the
+reference's so `load_state_dict(torch.load(ckpt)['model'])` works, with or without the
+`module.` prefix that `nn.DataParallel` adds (eval.py:309-315).
+
+What runs where
+  FeatureNet (mvsnet.py:10-30)            PyTorch-ROCm, all views of all batch items in one call
+  homography warp, variance volume,       hand-written gfx950 HIP kernels behind the C ABI
+  CostRegNet, softmax / soft-argmin /     (include/mvs_abi.h -> csrc/libmvs_hip.so), enqueued on
+  photometric confidence                  torch's current stream, one mvs_depth_infer per item
+
+Inference only: forward() raises in training mode, on CPU tensors, or if libmvs_hip.so is
+missing -- there is deliberately no PyTorch fallback for the HIP path.
+"""
+import threading
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .module import ConvBnReLU, ConvBnReLU3D
+
+
+class FeatureNet(nn.Module):
+    """2D feature extractor, unchanged torch ops (reference models/mvsnet.py:10-30)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)
+        self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)
+        self.conv2 = ConvBnReLU(8, 16, 5, 2, 2)
+        self.conv3 = ConvBnReLU(16, 16, 3, 1, 1)
+        self.conv4 = ConvBnReLU(16, 16, 3, 1, 1)
+        self.conv5 = ConvBnReLU(16, 32, 5, 2, 2)
+        self.conv6 = ConvBnReLU(32, 32, 3, 1, 1)
+        self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+
+    def forward(self, x):
+        x = self.conv1(self.conv0(x))
+        x = self.conv4(self.conv3(self.conv2(x)))
+        x = self.feature(self.conv6(self.conv5(x)))
+        return x
+
+
+class CostRegNet(nn.Module):
+    """Parameter container with the reference's names/shapes (models/mvsnet.py:33-62)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(32, 8)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
+        self.conv2 = ConvBnReLU3D(16, 16)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
+        self.conv4 = ConvBnReLU3D(32, 32)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
+        self.conv6 = ConvBnReLU3D(64, 64)
+        self.conv7 = nn.Sequential(
+            nn.ConvTranspose3d(64, 32, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.BatchNorm3d(32), nn.ReLU(inplace=True))
+        self.conv9 = nn.Sequential(
+            nn.ConvTranspose3d(32, 16, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.BatchNorm3d(16), nn.ReLU(inplace=True))
+        self.conv11 = nn.Sequential(
+            nn.ConvTranspose3d(16, 8, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.BatchNorm3d(8), nn.ReLU(inplace=True))
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+
+    def forward(self, x):  # pragma: no cover - never called on the product path
+        raise RuntimeError("CostRegNet runs inside libmvs_hip (mvs_costreg_forward)")
+
+    def bn_eps(self):
+        return float(self.conv0.bn.eps)
+
+
+class RefineNet(nn.Module):
+    """Parameter container only; the reference's RefineNet.forward is broken (mvsnet.py:85,238)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvBnReLU(4, 32)
+        self.conv2 = ConvBnReLU(32, 32)
+        self.conv3 = ConvBnReLU(32, 32)
+        self.res = ConvBnReLU(32, 1)
+
+
+class MVSNet(nn.Module):
+    def __init__(self, refine=True, debug=0):
+        super().__init__()
+        self.refine = refine
+        self.debug = debug
+        print('[MVSNet] init (debug={})'.format(self.debug))
+        if debug:
+            warnings.warn("debug visualisation bits (cv2.imshow in the reference, mvsnet.py:111-232) "
+                          "are ignored by the MI355X path")
+        self.feature = FeatureNet()
+        self.cost_regularization = CostRegNet()
+        if self.refine:
+            self.refine_network = RefineNet()
+        # per-device caches; plain attributes so nn.DataParallel replicas share them
+        self._cache_lock = threading.Lock()
+        self._blob_cache = {}       # device index -> (param versions, device blob tensor)
+        self._workspace_cache = {}  # (device index, N, D, h, w) -> uint8 device tensor
+
+    # -- caches ------------------------------------------------------------------------------
+    def _param_versions(self):
+        cr = self.cost_regularization
+        return tuple((t.data_ptr(), t._version) for t in list(cr.parameters()) + list(cr.buffers()))
+
+    def _weights_blob(self, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        versions = self._param_versions()
+        with self._cache_lock:
+            hit = self._blob_cache.get(key)
+            if hit is not None and hit[0] == versions:
+                return hit[1]
+            state = {k: v.detach().cpu() for k, v in self.cost_regularization.state_dict().items()}
+            blob = _lib.pack_weights(state, eps=self.cost_regularization.bn_eps()).to(device)
+            self._blob_cache[key] = (versions, blob)
+            return blob
+
+    def _workspace(self, device, N, D, h, w):
+        key = (device.index, N, D, h, w)
+        with self._cache_lock:
+            ws = self._workspace_cache.get(key)
+            if ws is None:
+                ws = _lib.alloc_workspace(N, 32, D, h, w, device)
+                self._workspace_cache[key] = ws
+            return ws
+
+    # -- forward -----------------------------------------------------------------------------
+    def forward(self, imgs, proj_matrices, depth_values):
+        n_imgs, n_proj = imgs.shape[1], proj_matrices.shape[1]
+        assert n_imgs == n_proj, "Different number of images and projection matrices"
+        if self.training:
+            raise RuntimeError("this MVSNet is the MI355X inference path; call .eval() "
+                               "(training, models/mvsnet.py:167-169, is out of scope)")
+        if not imgs.is_cuda:
+            raise RuntimeError("MVSNet.forward needs CUDA(ROCm) tensors: the depth path has no CPU "
+                               "implementation (got imgs on {})".format(imgs.device))
+        if self.refine:
+            raise NotImplementedError("refine=True: the reference's RefineNet path is broken "
+                                      "(F.cat at models/mvsnet.py:85); every working caller passes "
+                                      "refine=False (eval.py:308)")
+        device = imgs.device
+        B, N, _, H, W = imgs.shape
+        D = depth_values.shape[1]
+        with torch.cuda.device(device), torch.no_grad():
+            # step 1. feature extraction (reference mvsnet.py:125), all B*N images in one call
+            feats = self.feature(imgs.reshape(B * N, imgs.shape[2], H, W).to(torch.float32))
+            C, h, w = feats.shape[1], feats.shape[2], feats.shape[3]
+            feats = feats.reshape(B, N, C, h, w).contiguous()
+            proj = _lib._dev_f32(proj_matrices.to(device), "proj_matrices")
+            dv = _lib._dev_f32(depth_values.to(device), "depth_values")
+            blob = self._weights_blob(device)
+            ws = self._workspace(device, N, D, h, w)
+            depth = torch.empty((B, h, w), dtype=torch.float32, device=device)
+            conf = torch.empty((B, h, w), dtype=torch.float32, device=device)
+            # steps 2-4 (reference mvsnet.py:145-218): one enqueue per batch item, same stream
+            for b in range(B):
+                _lib.depth_infer(feats[b], proj[b], dv[b], blob, ws, depth[b], conf[b])
+        return {"depth": depth, "photometric_confidence": conf}

@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C ABI, ctypes) against
+  (1) golden vectors captured from the imported reference (tests/golden/fx_*.npz), and
+  (2) the CPU oracle (oracle/) on seeded inputs,
+stage by stage and end to end.  Tolerances are fp32 summation-order noise; the north_star
+bound (1e-3 relative L1 on depth) is asserted end to end with orders of magnitude to spare.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_conf_close, load_fixture, load_weights, rel_l1
+from oracle import oracle as orc
+from scene_3dreconstruction_mvsnet_amd import MVSNet, _lib, synthetic
+from scene_3dreconstruction_mvsnet_amd import module as hip_module
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def costreg_sd(fx=None):
+    sd = orc.costreg_state(load_weights())
+    if fx is not None and "prob_gain_extra" in fx:
+        sd = dict(sd)
+        sd["prob.weight"] = sd["prob.weight"] * fx["prob_gain_extra"]
+    return sd
+
+
+def blob_for(sd):
+    return _lib.pack_weights(sd).to(DEV)
+
+
+def hip_variance(feats, proj, dv):
+    """-> numpy [C,D,h,w] (reference layout) from the private [D,h,w,C] volume."""
+    N, C, h, w = feats.shape
+    D = dv.shape[0]
+    ws = _lib.alloc_workspace(N, C, D, h, w, DEV)
+    rt = _lib.relative_proj(cu(proj))
+    var = _lib.warp_variance(cu(feats), rt, cu(dv), ws)
+    torch.cuda.synchronize()
+    return var.permute(3, 0, 1, 2).contiguous().cpu().numpy()
+
+
+def hip_costreg(var_ncdhw, sd):
+    C, D, h, w = var_ncdhw.shape
+    var = cu(var_ncdhw).permute(1, 2, 3, 0).contiguous()
+    ws = _lib.alloc_workspace(1, C, D, h, w, DEV)
+    cost = _lib.costreg_forward(var, blob_for(sd), ws)
+    torch.cuda.synchronize()
+    return cost.cpu().numpy()
+
+
+def hip_depth_infer(feats, proj, dv, sd):
+    N, C, h, w = feats.shape
+    D = dv.shape[0]
+    ws = _lib.alloc_workspace(N, C, D, h, w, DEV)
+    depth = torch.empty((h, w), dtype=torch.float32, device=DEV)
+    conf = torch.empty_like(depth)
+    _lib.depth_infer(cu(feats), cu(proj), cu(dv), blob_for(sd), ws, depth, conf)
+    torch.cuda.synchronize()
+    return depth.cpu().numpy(), conf.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------ per-stage parity
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob"])
+def test_relative_proj(name):
+    fx = load_fixture(name)
+    proj = fx["proj_matrices"][0]
+    rt = _lib.relative_proj(cu(proj)).cpu().numpy()
+    for v in range(1, proj.shape[0]):
+        want = orc.relative_proj(proj[v], proj[0])
+        np.testing.assert_allclose(rt[v - 1], want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "oob"])
+def test_homo_warping_matches_reference(name):
+    fx = load_fixture(name)
+    feats, proj, dv = fx["features"], fx["proj_matrices"], fx["depth_values"]
+    for v in range(1, feats.shape[1]):
+        got = hip_module.homo_warping(cu(feats[:, v]), cu(proj[:, v]), cu(proj[:, 0]), cu(dv))
+        assert got.shape == fx["warped"][:, v - 1].shape
+        np.testing.assert_allclose(got.cpu().numpy(), fx["warped"][:, v - 1], rtol=0, atol=3e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob", "sharp"])
+def test_warp_variance_matches_reference(name):
+    fx = load_fixture(name)
+    got = hip_variance(fx["features"][0], fx["proj_matrices"][0], fx["depth_values"][0])
+    np.testing.assert_allclose(got, fx["variance"][0], rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "sharp"])
+def test_costreg_matches_reference(name):
+    fx = load_fixture(name)
+    got = hip_costreg(fx["variance"][0], costreg_sd(fx))
+    scale = max(np.abs(fx["cost_reg"][0]).max(), 1.0)
+    np.testing.assert_allclose(got, fx["cost_reg"][0], rtol=0, atol=3e-4 * scale)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "sharp", "cfg1"])
+def test_softargmin_conf_matches_reference(name):
+    fx = load_fixture(name)
+    depth, conf = _lib.softargmin_conf(cu(fx["cost_reg"][0]), cu(fx["depth_values"][0]))
+    depth, conf = depth.cpu().numpy(), conf.cpu().numpy()
+    np.testing.assert_allclose(depth, fx["depth"][0], rtol=0, atol=3e-3)  # ~450 mm scale
+    assert_conf_close(conf, fx["photometric_confidence"][0], fx["expected_index"][0],
+                      prob=fx["prob_volume"][0] if "prob_volume" in fx else None, atol=2e-5)
+
+
+def test_depth_regression_matches_reference():
+    fx = load_fixture("small")
+    got = hip_module.depth_regression(cu(fx["prob_volume"]), cu(fx["depth_values"]))
+    np.testing.assert_allclose(got.cpu().numpy(), fx["depth"], rtol=0, atol=3e-3)
+
+
+# ------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob", "b2", "cfg1", "sharp"])
+def test_depth_infer_matches_reference(name):
+    fx = load_fixture(name)
+    sd = costreg_sd(fx)
+    for b in range(fx["features"].shape[0]):
+        depth, conf = hip_depth_infer(fx["features"][b], fx["proj_matrices"][b],
+                                      fx["depth_values"][b], sd)
+        assert rel_l1(depth, fx["depth"][b]) < 1e-5  # north_star: 1e-3
+        assert_conf_close(conf, fx["photometric_confidence"][b], fx["expected_index"][b],
+                          prob=fx["prob_volume"][b] if "prob_volume" in fx else None, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "b2"])
+def test_mvsnet_module_forward_from_images(name):
+    """Drop-in module: images in, dict out (FeatureNet on PyTorch-ROCm + HIP path)."""
+    fx = load_fixture(name)
+    w = load_weights()
+    model = torch.nn.DataParallel(MVSNet(refine=False), device_ids=[0]).to(DEV)
+    model.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in w.items()})
+    model.eval()
+    out = model(cu(fx["imgs"]), cu(fx["proj_matrices"]), cu(fx["depth_values"]))
+    assert set(out.keys()) == {"depth", "photometric_confidence"}
+    assert out["depth"].dtype == torch.float32 and out["depth"].device.type == "cuda"
+    assert tuple(out["depth"].shape) == fx["depth"].shape
+    assert rel_l1(out["depth"].cpu().numpy(), fx["depth"]) < 1e-4
+    conf = out["photometric_confidence"].cpu().numpy()
+    frac_bad = (np.abs(conf - fx["photometric_confidence"]) > 5e-3).mean()
+    assert frac_bad < 0.02
+
+
+def test_weight_update_invalidates_blob_cache():
+    fx = load_fixture("tiny")
+    w = load_weights()
+    model = MVSNet(refine=False).to(DEV).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    args = (cu(fx["imgs"]), cu(fx["proj_matrices"]), cu(fx["depth_values"]))
+    d0 = model(*args)["depth"].clone()
+    with torch.no_grad():
+        model.cost_regularization.prob.weight.mul_(3.0)
+    d1 = model(*args)["depth"]
+    assert (d0 - d1).abs().max() > 1e-3
+    with torch.no_grad():
+        model.cost_regularization.prob.weight.div_(3.0)
+    d2 = model(*args)["depth"]
+    assert rel_l1(d2.cpu().numpy(), d0.cpu().numpy()) < 1e-6
+
+
+# ------------------------------------------------------------------------------ vs oracle, seeded
+@pytest.mark.parametrize("N,h,w,D,kw", [
+    (2, 8, 8, 8, {}),
+    (4, 24, 40, 32, dict(yaw_deg=2.0)),
+    (5, 32, 48, 24, dict(baseline=(-45.0, 12.0, 3.0))),
+    (7, 16, 16, 16, dict(baseline=(-12.0, 3.0, 1.0))),
+    (1, 16, 16, 8, {}),                      # single view: variance == 0 everywhere
+])
+def test_depth_infer_matches_oracle_random(N, h, w, D, kw):
+    feats = synthetic.random_features(N, 32, h, w, seed=11)
+    proj = synthetic.cameras(N, h, w, **kw)
+    dv = synthetic.depth_values(D)
+    sd = synthetic.random_costreg_state(seed=4)
+    var = orc.variance_volume(feats, proj, dv)
+    np.testing.assert_allclose(hip_variance(feats, proj, dv), var, rtol=0, atol=5e-4)
+    cost = orc.costreg_forward(var, sd)
+    np.testing.assert_allclose(hip_costreg(var, sd), cost, rtol=0,
+                               atol=3e-4 * max(np.abs(cost).max(), 1.0))
+    depth_o, conf_o, idx_o, prob_o = orc.softargmin_conf(cost, dv, want_prob=True)
+    depth, conf = hip_depth_infer(feats, proj, dv, sd)
+    assert rel_l1(depth, depth_o) < 1e-5
+    assert_conf_close(conf, conf_o, idx_o, prob=prob_o, atol=1e-3)
+
+
+def test_nonfinite_coordinates_give_nan_like_torch():
+    C, h, w = 32, 8, 8
+    fea = np.ones((1, C, h, w), np.float32)
+    ref = np.eye(4, dtype=np.float32)[None]
+    src = np.eye(4, dtype=np.float32)[None]
+    src[0, 2, 3] = -1.0
+    dv = np.array([[1.0, 2.0]], np.float32)
+    out = hip_module.homo_warping(cu(fea), cu(src), cu(ref), cu(dv)).cpu().numpy()
+    want = orc.homo_warp(fea[0], src[0], ref[0], dv[0])
+    assert np.isnan(out[0, :, 0]).all() and np.isfinite(out[0, :, 1]).all()
+    np.testing.assert_allclose(out[0][:, 1], want[:, 1], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------ error behaviour
+def test_bad_shapes_return_status_not_crash():
+    feats = torch.zeros((3, 32, 12, 16), device=DEV)  # h=12 not a multiple of 8
+    proj = torch.eye(4, device=DEV).repeat(3, 1, 1)
+    dv = torch.linspace(425, 500, 8, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    depth = torch.empty((12, 16), device=DEV)
+    with pytest.raises(_lib.MvsError) as e:
+        _lib.depth_infer(feats, proj, dv, ws, ws, depth, depth.clone())
+    assert e.value.code == 1
+    feats = torch.zeros((3, 32, 16, 16), device=DEV)
+    with pytest.raises(_lib.MvsError) as e:  # workspace too small
+        _lib.depth_infer(feats, proj, dv, ws, ws[:1024], depth, depth.clone())
+    assert e.value.code == 3
+
+
+# ------------------------------------------------------------------------------ full size (cfg2)
+@pytest.fixture(scope="module")
+def cfg2_problem():
+    c = synthetic.CONFIGS["cfg2"]
+    N, h, w, D = c["nviews"], c["H"] // 4, c["W"] // 4, c["D"]
+    feats = synthetic.random_features(N, 32, h, w, seed=0)
+    proj = synthetic.cameras(N, h, w)
+    dv = synthetic.depth_values(D, interval_scale=c["interval_scale"])
+    sd = synthetic.random_costreg_state(seed=0)
+    return feats, proj, dv, sd
+
+
+def test_cfg2_full_size_matches_oracle(cfg2_problem):
+    """BASELINE.json configs[1] (N=5, 640x512 -> 128x160, D=192) against the CPU oracle."""
+    feats, proj, dv, sd = cfg2_problem
+    depth, conf = hip_depth_infer(feats, proj, dv, sd)
+    depth_o, conf_o = orc.depth_infer(feats, proj, dv, sd)
+    assert np.isfinite(depth).all()
+    assert rel_l1(depth, depth_o) < 1e-4  # north_star: 1e-3
+    assert (np.abs(conf - conf_o) > 5e-3).mean() < 0.01
+
+
+def test_cfg2_properties(cfg2_problem):
+    """Size-independent properties at full size: determinism, range, source-view permutation
+    invariance (variance is symmetric in the source views) and world-scale equivariance."""
+    feats, proj, dv, sd = cfg2_problem
+    d0, c0 = hip_depth_infer(feats, proj, dv, sd)
+    d1, c1 = hip_depth_infer(feats, proj, dv, sd)
+    assert np.array_equal(d0, d1) and np.array_equal(c0, c1)
+    assert d0.min() >= dv[0] - 1e-3 and d0.max() <= dv[-1] + 1e-3
+    assert c0.min() >= 0 and c0.max() <= 1 + 1e-5
+    perm = [0, 3, 1, 4, 2]
+    dp, _ = hip_depth_infer(feats[perm], proj[perm], dv, sd)
+    assert rel_l1(dp, d0) < 1e-5
+    # scale the world by s: translations and depth hypotheses scale, sampling is unchanged
+    s = 2.0
+    proj_s = proj.copy()
+    proj_s[:, :3, 3] *= s
+    ds, cs = hip_depth_infer(feats, proj_s, dv * s, sd)
+    assert rel_l1(ds, d0 * s) < 1e-5
+    assert (np.abs(cs - c0) > 1e-3).mean() < 0.01
