@@ -17,8 +17,9 @@
  *  - Return value: MVS_OK or an error code; mvs_last_error_string() (thread-local) explains it.
  *    The library never aborts the process.
  *  - Re-entrant: no mutable global state besides the thread-local error string.
- *  - Volumes between stages use a PRIVATE channels-last layout ([D][h][w][C]); only the
- *    documented inputs/outputs below have reference layouts.
+ *  - Volumes between stages use a PRIVATE "C8-planar" layout: a C-channel volume is C/8 planes,
+ *    each a channels-last volume of 8 channels, [C/8][D][h][w][8].  Only the documented
+ *    inputs/outputs below have reference layouts.
  */
 #ifndef MVS_ABI_H
 #define MVS_ABI_H
@@ -84,26 +85,26 @@ int mvs_relative_proj(const float* proj, float* rt_out, int N, void* stream);
  *   feats         dev fp32 [N][C][h][w]   (FeatureNet outputs, view 0 = reference view)
  *   rt            dev fp32 [(N-1)][12]    (from mvs_relative_proj)
  *   depth_values  dev fp32 [D]
- *   var_out       dev, private layout [D][h][w][C] in `dtype`
+ *   var_out       dev, C8-planar [4][D][h][w][8] in `dtype`; must not alias the workspace
  *   workspace     dev, >= mvs_query_workspace bytes (uses the feature-transpose region only) */
 int mvs_warp_variance(const float* feats, const float* rt, const float* depth_values,
                       void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
                       int h, int w, int dtype, void* stream);
 
 /* 3D U-Net cost regularisation.  Replaces CostRegNet.forward, models/mvsnet.py:64-73.
- *   var           dev [D][h][w][32] in `dtype` (from mvs_warp_variance)
+ *   var           dev C8-planar [4][D][h][w][8] in `dtype` (from mvs_warp_variance)
  *   weights_blob  dev copy of the mvs_pack_weights blob
  *   cost_out      dev fp32 [D][h][w]  (== cost_reg.squeeze(1) of models/mvsnet.py:192) */
 int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_out,
                         void* workspace, size_t workspace_bytes, int D, int h, int w, int dtype,
                         void* stream);
 
-/* One CostRegNet layer (0..10, table above) on channels-last tensors: the building block of
+/* One CostRegNet layer (0..10, table above) on C8-planar tensors: the building block of
  * mvs_costreg_forward, exported for per-layer parity tests and per-kernel timing in bench.py.
  * Replaces one ConvBnReLU3D / ConvTranspose3d+BN+ReLU(+skip) / prob conv of
  * models/mvsnet.py:36-62.
- *   x     dev [Di][Hi][Wi][Cin]    skip  dev [Do][Ho][Wo][Cout] or NULL (layers 7..9 need it)
- *   y     dev [Do][Ho][Wo][Cout]   (layer 10: fp32 [D][h][w]) */
+ *   x     dev [Cin/8][Di][Hi][Wi][8]    skip  dev [Cout/8][Do][Ho][Wo][8] or NULL (layers 7..9
+ *   y     dev [Cout/8][Do][Ho][Wo][8]   need it)              (layer 10: y is fp32 [D][h][w]) */
 int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
                    int Di, int Hi, int Wi, int dtype, void* stream);
 

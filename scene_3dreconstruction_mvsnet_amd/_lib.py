@@ -167,11 +167,11 @@ def relative_proj(proj: torch.Tensor) -> torch.Tensor:
 
 
 def warp_variance(feats, rt, depth_values, workspace, dtype=MVS_F32):
-    """feats [N,32,h,w], rt [(N-1),12], depth_values [D] -> private volume tensor [D,h,w,32]."""
+    """feats [N,32,h,w], rt [(N-1),12], depth_values [D] -> C8-planar volume [4,D,h,w,8]."""
     feats = _dev_f32(feats, "features")
     N, C, h, w = feats.shape
     D = depth_values.shape[0]
-    var = torch.empty((D, h, w, C), dtype=torch.float32, device=feats.device)
+    var = torch.empty((C // 8, D, h, w, 8), dtype=torch.float32, device=feats.device)
     check(load().mvs_warp_variance(feats.data_ptr(), rt.data_ptr(),
                                    _dev_f32(depth_values, "depth_values").data_ptr(),
                                    var.data_ptr(), workspace.data_ptr(), workspace.numel(),
@@ -180,8 +180,8 @@ def warp_variance(feats, rt, depth_values, workspace, dtype=MVS_F32):
 
 
 def costreg_forward(var, blob, workspace, dtype=MVS_F32):
-    """var [D,h,w,32] (private layout) -> cost logits [D,h,w] fp32."""
-    D, h, w, _ = var.shape
+    """var [4,D,h,w,8] (C8-planar) -> cost logits [D,h,w] fp32."""
+    _, D, h, w, _ = var.shape
     cost = torch.empty((D, h, w), dtype=torch.float32, device=var.device)
     check(load().mvs_costreg_forward(var.data_ptr(), blob.data_ptr(), cost.data_ptr(),
                                      workspace.data_ptr(), workspace.numel(), D, h, w, dtype,
@@ -190,19 +190,18 @@ def costreg_forward(var, blob, workspace, dtype=MVS_F32):
 
 
 def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
-    """One CostRegNet layer on channels-last tensors [D,h,w,Cin] -> [D',h',w',Cout]."""
+    """One CostRegNet layer on C8-planar tensors [Cin/8,D,h,w,8] -> [Cout/8,D',h',w',8]."""
     ci, co = _LAYER_CH[layer]
-    Di, Hi, Wi, cin = x.shape
-    if cin != ci:
-        raise RuntimeError(f"layer {layer}: input has {cin} channels, expected {ci}")
+    planes, Di, Hi, Wi, c8 = x.shape
+    if planes * c8 != ci or c8 != 8:
+        raise RuntimeError(f"layer {layer}: input has {planes}x{c8} channels, expected {ci}")
     if 7 <= layer <= 9:
-        oshape = (2 * Di, 2 * Hi, 2 * Wi, co)
+        odims = (2 * Di, 2 * Hi, 2 * Wi)
     elif layer in (1, 3, 5):
-        oshape = ((Di - 1) // 2 + 1, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1, co)
+        odims = ((Di - 1) // 2 + 1, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1)
     else:
-        oshape = (Di, Hi, Wi, co)
-    if layer == 10:
-        oshape = oshape[:3]
+        odims = (Di, Hi, Wi)
+    oshape = odims if layer == 10 else (co // 8,) + odims + (8,)
     y = torch.empty(oshape, dtype=torch.float32, device=x.device)
     if skip is not None and tuple(skip.shape) != tuple(oshape):
         raise RuntimeError(f"layer {layer}: skip shape {tuple(skip.shape)} != {oshape}")
@@ -237,3 +236,15 @@ def depth_infer(feats, proj, depth_values, blob, workspace, depth_out, conf_out,
 def alloc_workspace(N, C, D, h, w, device, dtype=MVS_F32) -> torch.Tensor:
     nbytes = query_workspace(N, C, D, h, w, dtype)
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def to_c8(t: torch.Tensor) -> torch.Tensor:
+    """[C,D,h,w] (reference layout, one batch item) -> C8-planar [C/8,D,h,w,8]."""
+    C = t.shape[0]
+    return t.reshape(C // 8, 8, *t.shape[1:]).permute(0, 2, 3, 4, 1).contiguous()
+
+
+def from_c8(t: torch.Tensor) -> torch.Tensor:
+    """C8-planar [C/8,D,h,w,8] -> [C,D,h,w]."""
+    P, D, h, w, _ = t.shape
+    return t.permute(0, 4, 1, 2, 3).reshape(P * 8, D, h, w).contiguous()

@@ -4,14 +4,16 @@
 // ConvBnReLU3D block of models/module.py:26-33).  BatchNorm is already folded into the packed
 // weights (mvs_pack_weights), so each layer is  y = act(conv(x) + bias) (+ skip).
 //
-//   x    [Di][Hi][Wi][CIN]   channels-last fp32
-//   wgt  [27][CIN][COUT]     tap-major packed weights (tap = kd*9 + kh*3 + kw)
-//   y    [Do][Ho][Wo][COUT]
+//   x    [CIN/8][Di][Hi][Wi][8]    C8-planar fp32 (see warp_variance.hip)
+//   wgt  [27][CIN][COUT]           tap-major packed weights (tap = kd*9 + kh*3 + kw)
+//   y    [COUT/8][Do][Ho][Wo][8]   (COUT == 1: plain [Do][Ho][Wo])
 //
 // One thread = one output voxel x CPT output channels.  Weight addresses are wave-uniform, so
 // the compiler streams them through the scalar cache; activations are 16-byte vector loads that
 // hit L1/L2 for the 27-fold tap reuse.  The MFMA implicit-GEMM kernels in conv3d_mfma.hip
 // replace these on the FLOP-heavy layers; these stay as the generic fallback for every shape.
+#include <cstdlib>
+
 #include "mvs_internal.h"
 
 namespace mvs {
@@ -25,6 +27,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
                                                             int Wi, int Do, int Ho, int Wo) {
     constexpr int GROUPS = COUT / CPT;
     const size_t nvox = (size_t)Do * Ho * Wo;
+    const size_t nvox_in = (size_t)Di * Hi * Wi;
     const size_t vi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;  // output-channel group (wave-uniform)
     if (vi >= nvox) return;
@@ -70,11 +73,12 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
                     okw = iw >= 0 && iw < Wi;
                 }
                 if (!(okd && okh && okw)) continue;
-                const float* xp = x + (((size_t)id * Hi + ih) * Wi + iw) * CIN;
+                const size_t vin = ((size_t)id * Hi + ih) * Wi + iw;
                 const float* wp = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * CIN * COUT + co0;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ci += 4) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
+                    const float4 xv = *reinterpret_cast<const float4*>(
+                        x + ((size_t)(ci >> 3) * nvox_in + vin) * 8 + (ci & 7));
 #pragma unroll
                     for (int j = 0; j < CPT; ++j) {
                         acc[j] = fmaf(xv.x, wp[(ci + 0) * COUT + j], acc[j]);
@@ -86,14 +90,14 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
             }
         }
     }
-    float* yp = y + vi * COUT + co0;
-    const float* sp = SKIP ? skip + vi * COUT + co0 : nullptr;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
+        const int co = co0 + j;
+        const size_t o = (COUT == 1) ? vi : ((size_t)(co >> 3) * nvox + vi) * 8 + (co & 7);
         float v = acc[j];
         if (RELU) v = fmaxf(v, 0.0f);
-        if (SKIP) v += sp[j];  // skip + relu(bn(deconv(x)))   (models/mvsnet.py:69-71)
-        yp[j] = v;
+        if (SKIP) v += skip[o];  // skip + relu(bn(deconv(x)))   (models/mvsnet.py:69-71)
+        y[o] = v;
     }
 }
 
@@ -130,9 +134,23 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
     }
 }
 
-int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* wgt,
-                      const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
-    return launch_conv_layer_direct(layer, x, skip, y, wgt, bias, Di, Hi, Wi, dtype, s);
+// MVS_FORCE_DIRECT=1 routes every layer through the direct kernels (A/B checks in tests).
+static bool force_direct() {
+    static const bool v = [] {
+        const char* e = getenv("MVS_FORCE_DIRECT");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
+int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* blob,
+                      int Di, int Hi, int Wi, int dtype, hipStream_t s) {
+    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "conv3d: dtype %d not implemented", dtype);
+    const BlobLayout L = blob_layout();
+    if (layer == 0 && !force_direct())
+        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.b_off[0], Di, Hi, Wi, s);
+    return launch_conv_layer_direct(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer],
+                                    Di, Hi, Wi, dtype, s);
 }
 
 }  // namespace mvs

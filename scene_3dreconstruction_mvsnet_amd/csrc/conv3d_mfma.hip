@@ -1,0 +1,177 @@
+// conv3d_mfma.hip -- fp32-MFMA implicit-GEMM 3x3x3 convolutions for gfx950 (MI355X).
+//
+// conv0 of CostRegNet (32 -> 8 channels at full resolution; reference models/mvsnet.py:36,65 with
+// the ConvBnReLU3D block of models/module.py:26-33) is 68 % of the path's FLOPs.  It runs on
+// v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// GEMM shape.  Cout = 8 would fill only half of the MFMA's 16 columns, so the N dimension is
+// widened to  n = (j, co)  with j in {0,1} selecting one of two x-adjacent outputs ("pair"):
+//     M : output voxel pairs (z, y, xp)            16 pairs (32 voxels along x) per MFMA tile
+//     N : 16 = 2 outputs of the pair x 8 channels
+//     K : (kz, ky, kx', ci) with kx' in 0..3 spanning the 4 input columns a pair touches
+//     A[m][k] = in[z+kz-1][y+ky-1][2*xp+kx'-1][ci]
+//     B[k][n] = w[kz][ky][kx'-j][ci][co]  if 0 <= kx'-j <= 2 else 0    (Toeplitz-expanded weights)
+// 3/4 of the MFMA work is useful (K grows 27 -> 36 taps) instead of 1/2 with zero-padded columns.
+//
+// Blocking.  One block (256 threads, 4 waves) produces a 2(z) x 8(y) x 32(x) output tile.  K is
+// processed in 4 chunks of 8 input channels = one plane of the C8-planar input: per chunk the
+// 4 x 10 x 34 halo tile of that plane is staged in LDS (48-byte voxel stride: conflict-free
+// ds_read_b128 for the pair-strided A fragments), and the chunk's B panel (18 k-steps x 16 B per
+// lane, pre-packed in lane order by mvs_pack_weights) is held in registers (weight-stationary)
+// while the wave streams its 4 M-tiles' A fragments from LDS: one ds_read_b128 feeds 4 MFMAs.
+// LDS use is 65 KB per block -> 2 blocks per CU, so one block's fill overlaps the other's MFMAs.
+#include "mvs_internal.h"
+
+namespace mvs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace c0 {
+constexpr int TZ = 2, TY = 8, TX = 32;              // output tile
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;  // halo tile
+constexpr int VS = 12;                              // floats per voxel in LDS (8 data + 4 pad)
+constexpr int TILE_FLOATS = HZ * HY * HX * VS;      // 16320 floats = 65280 B
+constexpr int NPIECE = HZ * HY * HX * 2;            // 16-byte pieces per chunk (2720)
+constexpr int PIECES_PER_THREAD = (NPIECE + 255) / 256;  // 11
+constexpr int KS = 18;                              // k-steps of 16 per chunk (36 taps x 8 ci / 16)
+}  // namespace c0
+
+__global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
+    const float* __restrict__ x,     // [4][D][H][W][8]
+    const float* __restrict__ bp,    // [4 chunks][18 k-steps][64 lanes][4]  packed Toeplitz B
+    const float* __restrict__ bias,  // [8]
+    float* __restrict__ y,           // [D][H][W][8]
+    int D, int H, int W) {
+    using namespace c0;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const size_t V = (size_t)D * H * W;
+
+    // fill bookkeeping: piece -> (halo voxel, half); global offset or -1 when outside the volume
+    int goff[PIECES_PER_THREAD];
+    int loff[PIECES_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_THREAD; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, t = v / HX;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8 + half * 4) : -1;
+        loff[i] = (p < NPIECE) ? v * VS + half * 4 : -1;
+    }
+
+    // A-fragment addressing: lane (r = lane&15: pair index, g = lane>>4): k = (tap 2ks+(g>>1),
+    // ci 4(g&1)+j); halo x of the tap = 2r + kx' with kx' = kx0(ks) + (g>>1)
+    const int r = lane & 15, g = lane >> 4;
+    const int zt = wave >> 1, yt0 = 4 * (wave & 1);
+    const int lane_off = ((zt * HY + yt0) * HX + 2 * r + (g >> 1)) * VS + (g & 1) * 4;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < 4; ++c) {
+        // B panel of this chunk -> registers (coalesced 1 KiB per wave-load)
+        f32x4 breg[KS];
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) + (size_t)c * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) breg[ks] = bsrc[ks * 64];
+
+        // stage the halo tile of input plane c
+        const float* plane = x + (size_t)c * V * 8;
+        f32x4 stg[PIECES_PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_THREAD; ++i)
+            stg[i] = (goff[i] >= 0) ? *reinterpret_cast<const f32x4*>(plane + goff[i])
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();  // every wave is done reading the previous chunk's tile
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_THREAD; ++i)
+            if (loff[i] >= 0) *reinterpret_cast<f32x4*>(tile + loff[i]) = stg[i];
+        __syncthreads();
+
+        const float* abase = tile + lane_off;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int tap0 = 2 * ks;  // taps (kz, ky, kx') with kx' = tap % 4
+            const int kz = tap0 / 12, ky = (tap0 / 4) % 3, kx0 = tap0 % 4;
+            const int koff = ((kz * HY + ky) * HX + kx0) * VS;
+            f32x4 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(abase + koff + i * HX * VS);
+            const f32x4 bq = breg[ks];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D layout col n = lane&15 = (j, co), row m = 4*(lane>>4) + e = pair index
+    const int n = lane & 15, jj = n >> 3, co = n & 7;
+    const float bv = bias[co];
+    const int gz = z0 + zt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = y0 + yt0 + i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gx = x0 + 2 * m + jj;
+            if (gz < D && gy < H && gx < W) {
+                const float v = fmaxf(acc[i][e] + bv, 0.0f);  // ReLU(BN(conv)) with BN folded
+                y[(((size_t)gz * H + gy) * W + gx) * 8 + co] = v;
+            }
+        }
+    }
+}
+
+int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
+                      hipStream_t s) {
+    using namespace c0;
+    if ((size_t)D * H * W * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu floats exceeds 31-bit offsets",
+                    (size_t)D * H * W * 8);
+    const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+    conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
+                                              static_cast<float*>(y), D, H, W);
+    return check_hip(hipGetLastError(), "conv0_mfma launch");
+}
+
+// Host-side packing of the Toeplitz-expanded conv0 weights in per-lane fragment order.
+//   wfold [27][32][8]  BN-folded tap-major weights  ->  bp [4][18][64][4]
+void pack_conv0_pair_weights(const float* wfold, float* bp) {
+    using namespace c0;
+    for (int c = 0; c < 4; ++c)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const int g = lane >> 4, n = lane & 15;
+                    const int tap = 2 * ks + (g >> 1);
+                    const int kz = tap / 12, ky = (tap / 4) % 3, kxp = tap % 4;
+                    const int ci = 8 * c + 4 * (g & 1) + j4;
+                    const int jj = n >> 3, co = n & 7;
+                    const int kx = kxp - jj;
+                    float v = 0.0f;
+                    if (kx >= 0 && kx <= 2) v = wfold[((size_t)(kz * 9 + ky * 3 + kx) * 32 + ci) * 8 + co];
+                    bp[(((size_t)c * KS + ks) * 64 + lane) * 4 + j4] = v;
+                }
+}
+
+}  // namespace mvs

@@ -107,6 +107,7 @@ int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_pa
                 }
         }
     }
+    pack_conv0_pair_weights(blob + L.w_off[0], blob + L.c0p_off);
     return MVS_OK;
 }
 
@@ -130,7 +131,7 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
         return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
-    if (int st = launch_nchw_to_nhwc(feats, feats_t, N, C, h, w, s)) return st;
+    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, s)) return st;
     return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
 }
 
@@ -150,12 +151,10 @@ int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     const float* blob = static_cast<const float*>(weights_blob);
-    const BlobLayout L = blob_layout();
     auto act = [&](int l) { return static_cast<void*>(ws + W.act[l]); };
     auto run = [&](int l, const void* x, const void* skip, void* y) {
         const int lv = kLayers[l].level_in;
-        return launch_conv_layer(l, x, skip, y, blob + L.w_off[l], blob + L.b_off[l], D >> lv,
-                                 h >> lv, w >> lv, dtype, s);
+        return launch_conv_layer(l, x, skip, y, blob, D >> lv, h >> lv, w >> lv, dtype, s);
     };
     // models/mvsnet.py:64-73
     int st;
@@ -181,10 +180,8 @@ int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const vo
     if (S.kind == kDeconv && !skip) return fail(MVS_ERR_NULL, "layer %d needs its skip tensor", layer);
     if (Di < 1 || Hi < 1 || Wi < 1 || (S.stride == 2 && S.kind == kConv && ((Di | Hi | Wi) & 1)))
         return fail(MVS_ERR_BAD_SHAPE, "layer %d: input dims %d,%d,%d unsupported", layer, Di, Hi, Wi);
-    const BlobLayout L = blob_layout();
-    const float* blob = static_cast<const float*>(weights_blob);
-    return launch_conv_layer(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer], Di, Hi,
-                             Wi, dtype, static_cast<hipStream_t>(stream));
+    return launch_conv_layer(layer, x, skip, y, static_cast<const float*>(weights_blob), Di, Hi, Wi,
+                             dtype, static_cast<hipStream_t>(stream));
 }
 
 int mvs_softargmin_conf(const float* cost, const float* depth_values, float* depth_out,

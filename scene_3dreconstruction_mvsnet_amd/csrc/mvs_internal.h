@@ -39,6 +39,7 @@ constexpr LayerSpec kLayers[MVS_NUM_LAYERS] = {
 struct BlobLayout {
     size_t w_off[MVS_NUM_LAYERS];  // in floats
     size_t b_off[MVS_NUM_LAYERS];  // in floats
+    size_t c0p_off;                // conv0 Toeplitz "pair" panel [4][18][64][4] (conv3d_mfma.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -52,6 +53,8 @@ inline BlobLayout blob_layout() {
         off += (size_t)kLayers[l].cout;
         off = (off + 63) & ~(size_t)63;
     }
+    L.c0p_off = off;
+    off += (size_t)4 * 18 * 64 * 4;
     L.total_floats = off;
     return L;
 }
@@ -60,10 +63,10 @@ inline size_t dtype_size(int dtype) { return dtype == MVS_F32 ? 4 : 2; }
 
 // Device workspace carve-up (byte offsets, 256-byte aligned).
 struct Workspace {
-    size_t feats_t;  // [N][h][w][C] fp32 channels-last copy of the features
+    size_t feats_t;  // [4][N][h][w][8] fp32 C8-planar copy of the features
     size_t rt;       // [(N-1)][12] fp32
-    size_t var;      // [D][h][w][32]
-    size_t act[10];  // outputs of layers 0..9 (channels-last, storage dtype)
+    size_t var;      // [4][D][h][w][8]
+    size_t act[10];  // outputs of layers 0..9 (C8-planar, storage dtype)
     size_t cost;     // [D][h][w] fp32
     size_t total;
 };
@@ -93,14 +96,19 @@ int fail(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // kernel launchers (implemented in the .hip files); all enqueue on `s` and return a status
-int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int h, int w, hipStream_t s);
+int launch_nchw_to_c8(const float* in, float* out, int N, int C, int h, int w, hipStream_t s);
 int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s);
 int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s);
 int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,
                      int h, int w, hipStream_t s);
-int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* wgt,
-                      const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
+int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* blob,
+                      int Di, int Hi, int Wi, int dtype, hipStream_t s);
+int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y, const float* wgt,
+                             const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
+int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
+                      hipStream_t s);
+void pack_conv0_pair_weights(const float* wfold, float* bp);
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s);
 int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,

@@ -5,10 +5,12 @@
 //   models/module.py:96-139   homo_warping (per source view)
 //   models/mvsnet.py:145-177  ref-volume repeat, sum / sum-of-squares accumulation, variance
 //
-// Data layout.  Features arrive NCHW fp32 from FeatureNet; nchw_to_nhwc_kernel re-lays them
-// channels-last ([N][h][w][32]) so that one bilinear tap of one view is ONE 128-byte line.  The
-// variance volume is written channels-last ([D][h][w][32]): 8 lanes cover one voxel (4 channels
-// = 16 B each), so a wave64 store instruction writes 8 voxels x 128 B = 1 KiB contiguous.
+// Data layout ("C8-planar", private to the HIP path): a tensor of C channels is stored as C/8
+// planes, each a channels-last volume of 8 channels: [C/8][D][h][w][8].  Features arrive NCHW
+// fp32 from FeatureNet; nchw_to_c8_kernel re-lays them as [4][N][h][w][8] so that a bilinear tap
+// of 8 channels is 32 contiguous bytes and x-adjacent taps share 128-byte lines.  The variance
+// volume is written as [4][D][h][w][8], the layout the conv3d kernels stage into LDS one plane
+// (= one K-chunk of 8 input channels) at a time.
 //
 // HBM-bound: algorithmic bytes per map = N*32*h*w*4 (features) + 32*D*h*w*es (volume write).
 #include "mvs_internal.h"
@@ -16,36 +18,38 @@
 namespace mvs {
 
 // ---------------------------------------------------------------------------------------------
-// [N][C=32][h][w] -> [N][h][w][32]; one block transposes 32 channels x 64 pixels through LDS.
+// [N][C=32][h][w] -> C8-planar [4][N][h][w][8]; one block transposes 32 channels x 64 pixels
+// through LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
-                                                           float* __restrict__ out, int hw) {
+__global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, int N, int hw) {
     __shared__ float tile[32][65];
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
     const float* src = in + (size_t)n * 32 * hw;
-    float* dst = out + (size_t)n * 32 * hw;
 #pragma unroll
     for (int c = ty; c < 32; c += 4) {
         const int p = p0 + tx;
         tile[c][tx] = (p < hw) ? src[(size_t)c * hw + p] : 0.0f;
     }
     __syncthreads();
-    const int c = threadIdx.x & 31, pr = threadIdx.x >> 5;  // 32 x 8
+    const int c8 = threadIdx.x & 7, pp = threadIdx.x >> 3;  // 8 channels x 32 pixels per pass
 #pragma unroll
-    for (int pp = pr; pp < 64; pp += 8) {
-        const int p = p0 + pp;
-        if (p < hw) dst[(size_t)p * 32 + c] = tile[c][pp];
-    }
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int q = pass * 32 + pp, p = p0 + q;
+            if (p < hw) out[(((size_t)pl * N + n) * hw + p) * 8 + c8] = tile[pl * 8 + c8][q];
+        }
 }
 
-int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int h, int w, hipStream_t s) {
+int launch_nchw_to_c8(const float* in, float* out, int N, int C, int h, int w, hipStream_t s) {
     (void)C;
     const int hw = h * w;
     dim3 grid((hw + 63) / 64, N);
-    nchw_to_nhwc_kernel<<<grid, 256, 0, s>>>(in, out, hw);
-    return check_hip(hipGetLastError(), "nchw_to_nhwc launch");
+    nchw_to_c8_kernel<<<grid, 256, 0, s>>>(in, out, N, hw);
+    return check_hip(hipGetLastError(), "nchw_to_c8 launch");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -150,35 +154,47 @@ __device__ __forceinline__ Tap make_tap(float qx, float qy, float qz, float tx, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused warp + variance.  Block = 256 threads = 32 pixels (along x) x 8 channel-chunks; each
-// block walks a slab of DS depths so consecutive depths re-use the same source lines from L1/L2
-// (the epipolar shift per depth step is a fraction of a pixel).
-//   feats_t [N][h][w][32], rt [(N-1)][12], dv [D] -> var [D][h][w][32]
+// Fused warp + variance.  Thread = (pixel, half): it owns channels {8*pl + 4*half .. +3} of its
+// pixel for all four channel planes pl, so the sampling coordinates of a (pixel, depth, view)
+// are computed once and reused for 16 channels.  A wave covers 32 consecutive pixels; each of
+// its stores writes 32 px x 32 B = 1 KiB contiguous into one plane of the C8-planar volume.
+// Each block walks a slab of depths so consecutive depths re-use the same source lines from
+// L1/L2 (the epipolar shift per depth step is a fraction of a pixel).
+//   feats_p [4][N][h][w][8], rt [(N-1)][12], dv [D] -> var [4][D][h][w][8]
 // ---------------------------------------------------------------------------------------------
-constexpr int kWarpDepthSlab = 16;
+constexpr int kWarpDepthSlab = 8;
+constexpr int kWarpPixPerBlock = 128;
 
-__global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restrict__ feats_t,
+__global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restrict__ feats_p,
                                                             const float* __restrict__ rt,
                                                             const float* __restrict__ dv,
                                                             float* __restrict__ var, int N, int D,
                                                             int h, int w) {
-    const int q = threadIdx.x & 7;          // channel chunk: channels 4q..4q+3
-    const int px = threadIdx.x >> 3;        // 0..31
-    const int xblocks = (w + 31) / 32;
-    const int y = blockIdx.x / xblocks;
-    const int x = (blockIdx.x % xblocks) * 32 + px;
+    const int half = threadIdx.x & 1;
+    const int hw = h * w;
+    const int p = blockIdx.x * kWarpPixPerBlock + (threadIdx.x >> 1);
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
     const int d0 = blockIdx.y * kWarpDepthSlab;
-    if (x >= w) return;
-    const size_t hw = (size_t)h * w;
+    const int d1 = min(d0 + kWarpDepthSlab, D);
+    const size_t plane_stride = (size_t)N * hw * 8;  // floats between channel planes
     const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
-    const float4 ref = *reinterpret_cast<const float4*>(feats_t + ((size_t)y * w + x) * 32 + 4 * q);
     const float fx = (float)x, fy = (float)y;
     const float inv_n = 1.0f / (float)N;
-    const int d1 = min(d0 + kWarpDepthSlab, D);
+    float4 ref[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+        ref[pl] = *reinterpret_cast<const float4*>(feats_p + pl * plane_stride + (size_t)p * 8 + 4 * half);
+    const size_t V0 = (size_t)D * hw;
     for (int d = d0; d < d1; ++d) {
         const float depth = dv[d];
-        float4 S = ref;
-        float4 Q = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+        float4 S[4], Q[4];
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            S[pl] = ref[pl];
+            Q[pl] = make_float4(ref[pl].x * ref[pl].x, ref[pl].y * ref[pl].y, ref[pl].z * ref[pl].z,
+                                ref[pl].w * ref[pl].w);
+        }
         bool any_nan = false;
         for (int v = 1; v < N; ++v) {
             const float* r = rt + (size_t)(v - 1) * 12;
@@ -187,38 +203,45 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
             const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
             const Tap t = make_tap(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w);
             any_nan |= t.nan;
-            const float* f = feats_t + (size_t)v * hw * 32 + (size_t)t.off * 32 + 4 * q;
-            const float4 a = *reinterpret_cast<const float4*>(f);
-            const float4 b = *reinterpret_cast<const float4*>(f + 32);
-            const float4 c = *reinterpret_cast<const float4*>(f + (size_t)w * 32);
-            const float4 e = *reinterpret_cast<const float4*>(f + (size_t)w * 32 + 32);
-            float4 wv;
-            wv.x = fmaf(a.x, t.w00, fmaf(b.x, t.w01, fmaf(c.x, t.w10, e.x * t.w11)));
-            wv.y = fmaf(a.y, t.w00, fmaf(b.y, t.w01, fmaf(c.y, t.w10, e.y * t.w11)));
-            wv.z = fmaf(a.z, t.w00, fmaf(b.z, t.w01, fmaf(c.z, t.w10, e.z * t.w11)));
-            wv.w = fmaf(a.w, t.w00, fmaf(b.w, t.w01, fmaf(c.w, t.w10, e.w * t.w11)));
-            S.x += wv.x; S.y += wv.y; S.z += wv.z; S.w += wv.w;
-            Q.x = fmaf(wv.x, wv.x, Q.x); Q.y = fmaf(wv.y, wv.y, Q.y);
-            Q.z = fmaf(wv.z, wv.z, Q.z); Q.w = fmaf(wv.w, wv.w, Q.w);
+            const float* f0 = feats_p + ((size_t)v * hw + t.off) * 8 + 4 * half;
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const float* f = f0 + pl * plane_stride;
+                const float4 a = *reinterpret_cast<const float4*>(f);
+                const float4 b = *reinterpret_cast<const float4*>(f + 8);
+                const float4 c = *reinterpret_cast<const float4*>(f + (size_t)w * 8);
+                const float4 e = *reinterpret_cast<const float4*>(f + (size_t)w * 8 + 8);
+                float4 wv;
+                wv.x = fmaf(a.x, t.w00, fmaf(b.x, t.w01, fmaf(c.x, t.w10, e.x * t.w11)));
+                wv.y = fmaf(a.y, t.w00, fmaf(b.y, t.w01, fmaf(c.y, t.w10, e.y * t.w11)));
+                wv.z = fmaf(a.z, t.w00, fmaf(b.z, t.w01, fmaf(c.z, t.w10, e.z * t.w11)));
+                wv.w = fmaf(a.w, t.w00, fmaf(b.w, t.w01, fmaf(c.w, t.w10, e.w * t.w11)));
+                S[pl].x += wv.x; S[pl].y += wv.y; S[pl].z += wv.z; S[pl].w += wv.w;
+                Q[pl].x = fmaf(wv.x, wv.x, Q[pl].x); Q[pl].y = fmaf(wv.y, wv.y, Q[pl].y);
+                Q[pl].z = fmaf(wv.z, wv.z, Q[pl].z); Q[pl].w = fmaf(wv.w, wv.w, Q[pl].w);
+            }
         }
-        // var = Q/N - (S/N)^2        (models/mvsnet.py:177)
-        float4 o;
-        float m;
-        m = S.x * inv_n; o.x = fmaf(-m, m, Q.x * inv_n);
-        m = S.y * inv_n; o.y = fmaf(-m, m, Q.y * inv_n);
-        m = S.z * inv_n; o.z = fmaf(-m, m, Q.z * inv_n);
-        m = S.w * inv_n; o.w = fmaf(-m, m, Q.w * inv_n);
-        if (any_nan) o = make_float4(NAN, NAN, NAN, NAN);
-        *reinterpret_cast<float4*>(var + (((size_t)d * h + y) * w + x) * 32 + 4 * q) = o;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            // var = Q/N - (S/N)^2        (models/mvsnet.py:177)
+            float4 o;
+            float m;
+            m = S[pl].x * inv_n; o.x = fmaf(-m, m, Q[pl].x * inv_n);
+            m = S[pl].y * inv_n; o.y = fmaf(-m, m, Q[pl].y * inv_n);
+            m = S[pl].z * inv_n; o.z = fmaf(-m, m, Q[pl].z * inv_n);
+            m = S[pl].w * inv_n; o.w = fmaf(-m, m, Q[pl].w * inv_n);
+            if (any_nan) o = make_float4(NAN, NAN, NAN, NAN);
+            *reinterpret_cast<float4*>(var + ((size_t)pl * V0 + (size_t)d * hw + p) * 8 + 4 * half) = o;
+        }
     }
 }
 
-int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
+int launch_warp_variance(const float* feats_p, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s) {
     if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "warp_variance: dtype %d not implemented", dtype);
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
-    dim3 grid(((w + 31) / 32) * h, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
-    warp_variance_kernel<<<grid, 256, 0, s>>>(feats_t, rt, dv, static_cast<float*>(var), N, D, h, w);
+    dim3 grid((h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
+    warp_variance_kernel<<<grid, 256, 0, s>>>(feats_p, rt, dv, static_cast<float*>(var), N, D, h, w);
     return check_hip(hipGetLastError(), "warp_variance launch");
 }
 

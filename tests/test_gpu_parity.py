@@ -35,19 +35,19 @@ def blob_for(sd):
 
 
 def hip_variance(feats, proj, dv):
-    """-> numpy [C,D,h,w] (reference layout) from the private [D,h,w,C] volume."""
+    """-> numpy [C,D,h,w] (reference layout) from the private C8-planar volume."""
     N, C, h, w = feats.shape
     D = dv.shape[0]
     ws = _lib.alloc_workspace(N, C, D, h, w, DEV)
     rt = _lib.relative_proj(cu(proj))
     var = _lib.warp_variance(cu(feats), rt, cu(dv), ws)
     torch.cuda.synchronize()
-    return var.permute(3, 0, 1, 2).contiguous().cpu().numpy()
+    return _lib.from_c8(var).cpu().numpy()
 
 
 def hip_costreg(var_ncdhw, sd):
     C, D, h, w = var_ncdhw.shape
-    var = cu(var_ncdhw).permute(1, 2, 3, 0).contiguous()
+    var = _lib.to_c8(cu(var_ncdhw))
     ws = _lib.alloc_workspace(1, C, D, h, w, DEV)
     cost = _lib.costreg_forward(var, blob_for(sd), ws)
     torch.cuda.synchronize()
@@ -115,6 +115,41 @@ def test_depth_regression_matches_reference():
     fx = load_fixture("small")
     got = hip_module.depth_regression(cu(fx["prob_volume"]), cu(fx["depth_values"]))
     np.testing.assert_allclose(got.cpu().numpy(), fx["depth"], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize("D,h,w", [(8, 8, 8), (8, 16, 40), (16, 24, 72), (10, 8, 96)])
+def test_conv0_mfma_matches_oracle(D, h, w):
+    """The fp32-MFMA conv0 kernel (Toeplitz pair panel, ragged x tiles) against the oracle."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((32, D, h, w)).astype(np.float32)
+    sd = synthetic.random_costreg_state(seed=9)
+    want = orc.conv3d(x, sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
+    got = _lib.from_c8(_lib.conv_layer(0, _lib.to_c8(cu(x)), None, blob_for(sd))).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1.0))
+
+
+@pytest.mark.parametrize("layer", list(range(11)))
+def test_every_layer_matches_oracle(layer):
+    """mvs_conv_layer for each CostRegNet layer on random C8-planar input vs the oracle."""
+    ci, co = _lib._LAYER_CH[layer]
+    rng = np.random.default_rng(layer)
+    D, h, w = (8, 8, 16)
+    x = rng.standard_normal((ci, D, h, w)).astype(np.float32)
+    sd = synthetic.random_costreg_state(seed=3)
+    blob = blob_for(sd)
+    key = _lib.CONV_WEIGHT_KEYS[layer]
+    if layer == 10:
+        want = orc.conv3d(x, sd[key], bias=sd["prob.bias"], bn=None, relu=False)[0]
+        got = _lib.conv_layer(10, _lib.to_c8(cu(x)), None, blob).cpu().numpy()
+    elif layer >= 7:
+        skip = rng.standard_normal((co, 2 * D, 2 * h, 2 * w)).astype(np.float32)
+        want = skip + orc.deconv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]))
+        got = _lib.from_c8(_lib.conv_layer(layer, _lib.to_c8(cu(x)), _lib.to_c8(cu(skip)), blob)).cpu().numpy()
+    else:
+        stride = 2 if layer in (1, 3, 5) else 1
+        want = orc.conv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]), stride=stride)
+        got = _lib.from_c8(_lib.conv_layer(layer, _lib.to_c8(cu(x)), None, blob)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1.0))
 
 
 # ------------------------------------------------------------------------------ end to end

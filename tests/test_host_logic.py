@@ -77,6 +77,20 @@ def test_pack_weights_folds_bn_and_relayouts():
         off = (off + 27 * ci * co + 63) // 64 * 64
         np.testing.assert_allclose(blob[off:off + co], shift, rtol=2e-6, atol=1e-7)
         off = (off + co + 63) // 64 * 64
+    # conv0 "pair" panel for the MFMA kernel: Toeplitz-expanded [4 chunks][18 k-steps][64][4]
+    panel = blob[off:off + 4 * 18 * 64 * 4].reshape(4, 18, 64, 4)
+    w0 = blob[:27 * 32 * 8].reshape(3, 3, 3, 32, 8)  # folded conv0 weights [kz][ky][kx][ci][co]
+    for c, ks, lane in [(0, 0, 0), (1, 5, 17), (2, 9, 40), (3, 17, 63), (0, 3, 57), (2, 12, 9)]:
+        g, n = lane >> 4, lane & 15
+        tap = 2 * ks + (g >> 1)
+        kz, ky, kxp = tap // 12, (tap // 4) % 3, tap % 4
+        j, co = n >> 3, n & 7
+        for j4 in range(4):
+            ci = 8 * c + 4 * (g & 1) + j4
+            kx = kxp - j
+            want = w0[kz, ky, kx, ci, co] if 0 <= kx <= 2 else 0.0
+            assert panel[c, ks, lane, j4] == want
+    off += 4 * 18 * 64 * 4
     assert off * 4 == _lib.query_weights_blob()
 
 
