@@ -25,27 +25,42 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
                                                             const float* __restrict__ skip,
                                                             float* __restrict__ y, int Di, int Hi,
                                                             int Wi, int Do, int Ho, int Wo) {
-    constexpr int GROUPS = COUT / CPT;
     const size_t nvox = (size_t)Do * Ho * Wo;
     const size_t nvox_in = (size_t)Di * Hi * Wi;
-    const size_t vi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;  // output-channel group (wave-uniform)
-    if (vi >= nvox) return;
-    const int ow = (int)(vi % Wo), oh = (int)((vi / Wo) % Ho), od = (int)(vi / ((size_t)Wo * Ho));
     const int co0 = g * CPT;
-    (void)GROUPS;
+    int ow, oh, od;
+    size_t vi;
+    if (DECONV) {
+        // blockIdx.z = parity class (pd,ph,pw) of the output voxel: o = 2*i - 1 + k has solutions
+        // k = 1 (o even) or k in {0, 2} (o odd), so the tap set is uniform across the block and
+        // only the 27/8 useful taps on average are visited.
+        const size_t ci = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // index inside the class
+        if (ci >= nvox_in) return;
+        const int pw = blockIdx.z & 1, ph = (blockIdx.z >> 1) & 1, pd = blockIdx.z >> 2;
+        ow = 2 * (int)(ci % Wi) + pw;
+        oh = 2 * (int)((ci / Wi) % Hi) + ph;
+        od = 2 * (int)(ci / ((size_t)Wi * Hi)) + pd;
+        vi = ((size_t)od * Ho + oh) * Wo + ow;
+    } else {
+        vi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (vi >= nvox) return;
+        ow = (int)(vi % Wo); oh = (int)((vi / Wo) % Ho); od = (int)(vi / ((size_t)Wo * Ho));
+    }
 
     float acc[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) acc[j] = bias[co0 + j];
 
+    const int pcls = DECONV ? (int)blockIdx.z : 0;
     for (int kd = 0; kd < 3; ++kd) {
         int id;
         bool okd;
         if (DECONV) {
+            if (((kd & 1) != 0) == (((pcls >> 2) & 1) != 0)) continue;  // wave-uniform parity skip
             const int t = od + 1 - kd;  // o = 2*i - 1 + k
             id = t >> 1;
-            okd = (t >= 0) && !(t & 1) && id < Di;
+            okd = (t >= 0) && id < Di;
         } else {
             id = od * STRIDE + kd - 1;
             okd = id >= 0 && id < Di;
@@ -54,9 +69,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
             int ih;
             bool okh;
             if (DECONV) {
+                if (((kh & 1) != 0) == (((pcls >> 1) & 1) != 0)) continue;
                 const int t = oh + 1 - kh;
                 ih = t >> 1;
-                okh = (t >= 0) && !(t & 1) && ih < Hi;
+                okh = (t >= 0) && ih < Hi;
             } else {
                 ih = oh * STRIDE + kh - 1;
                 okh = ih >= 0 && ih < Hi;
@@ -65,9 +81,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
                 int iw;
                 bool okw;
                 if (DECONV) {
+                    if (((kw & 1) != 0) == ((pcls & 1) != 0)) continue;
                     const int t = ow + 1 - kw;
                     iw = t >> 1;
-                    okw = (t >= 0) && !(t & 1) && iw < Wi;
+                    okw = (t >= 0) && iw < Wi;
                 } else {
                     iw = ow * STRIDE + kw - 1;
                     okw = iw >= 0 && iw < Wi;
@@ -107,8 +124,8 @@ static int run_direct(const void* x, const void* skip, void* y, const float* wgt
     int Do, Ho, Wo;
     if (DECONV) { Do = 2 * Di; Ho = 2 * Hi; Wo = 2 * Wi; }
     else { Do = (Di - 1) / STRIDE + 1; Ho = (Hi - 1) / STRIDE + 1; Wo = (Wi - 1) / STRIDE + 1; }
-    const size_t nvox = (size_t)Do * Ho * Wo;
-    dim3 grid((unsigned)((nvox + 255) / 256), COUT / CPT);
+    const size_t nthreads = DECONV ? (size_t)Di * Hi * Wi : (size_t)Do * Ho * Wo;
+    dim3 grid((unsigned)((nthreads + 255) / 256), COUT / CPT, DECONV ? 8 : 1);
     conv3d_direct_kernel<CIN, COUT, CPT, STRIDE, DECONV, RELU, SKIP><<<grid, 256, 0, s>>>(
         static_cast<const float*>(x), wgt, bias, static_cast<const float*>(skip),
         static_cast<float*>(y), Di, Hi, Wi, Do, Ho, Wo);
@@ -123,10 +140,10 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
         case 1: return run_direct<8, 16, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 2: return run_direct<16, 16, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 3: return run_direct<16, 32, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 4: return run_direct<32, 32, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 5: return run_direct<32, 64, 16, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 6: return run_direct<64, 64, 16, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 7: return run_direct<64, 32, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 4: return run_direct<32, 32, 8, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 5: return run_direct<32, 64, 4, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 6: return run_direct<64, 64, 4, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 7: return run_direct<64, 32, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 8: return run_direct<32, 16, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 9: return run_direct<16, 8, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 10: return run_direct<8, 1, 1, 1, false, false, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
