@@ -118,6 +118,159 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose3d k3 s2 p1 op1 (+folded BN) + ReLU + skip, gather form.
+//   y[o] += x[i] * w[k]  for  o = 2*i - 1 + k  per axis  =>  even o: (k=1, i=o/2);
+//   odd o: (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
+// blockIdx.z = (pd, ph): parity class of the output z/y, so the z/y tap set is block-uniform.
+// A thread owns input voxel (zi, yi, xi) and produces BOTH x-parities (ow = 2xi, 2xi+1): 64 B
+// contiguous per thread for 8 channels, fully coalesced across the wave; the x taps are
+//   even: x[xi]*w[kw=1]            odd: x[xi]*w[kw=2] + x[xi+1]*w[kw=0].
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int CPT>
+__global__ __launch_bounds__(256) void deconv3d_direct_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ skip,
+                                                              float* __restrict__ y, int Di, int Hi,
+                                                              int Wi) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t nvox_in = (size_t)Di * Hi * Wi, nvox = nvox_in * 8;
+    const size_t ti = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= nvox_in) return;
+    const int co0 = blockIdx.y * CPT;
+    const int ph = blockIdx.z & 1, pd = blockIdx.z >> 1;
+    const int xi = (int)(ti % Wi), yi = (int)((ti / Wi) % Hi), zi = (int)(ti / ((size_t)Wi * Hi));
+    const int od = 2 * zi + pd, oh = 2 * yi + ph;
+
+    float acc0[CPT], acc1[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { acc0[j] = bias[co0 + j]; acc1[j] = acc0[j]; }
+
+    const bool x1ok = xi + 1 < Wi;
+    for (int kd = 0; kd < 3; ++kd) {
+        if ((kd & 1) == pd) continue;  // block-uniform
+        const int id = (od + 1 - kd) >> 1;
+        if (id >= Di) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            if ((kh & 1) == ph) continue;
+            const int ih = (oh + 1 - kh) >> 1;
+            if (ih >= Hi) continue;
+            const size_t vin = ((size_t)id * Hi + ih) * Wi + xi;
+            const float* w0 = wgt + (size_t)((kd * 3 + kh) * 3 + 0) * CIN * COUT + co0;
+            const float* w1 = w0 + CIN * COUT;
+            const float* w2 = w1 + CIN * COUT;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci += 4) {
+                const float* xp = x + ((size_t)(ci >> 3) * nvox_in + vin) * 8 + (ci & 7);
+                const float4 a = *reinterpret_cast<const float4*>(xp);
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (x1ok) b = *reinterpret_cast<const float4*>(xp + 8);
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    acc0[j] = fmaf(a.x, w1[(ci + 0) * COUT + j], acc0[j]);
+                    acc0[j] = fmaf(a.y, w1[(ci + 1) * COUT + j], acc0[j]);
+                    acc0[j] = fmaf(a.z, w1[(ci + 2) * COUT + j], acc0[j]);
+                    acc0[j] = fmaf(a.w, w1[(ci + 3) * COUT + j], acc0[j]);
+                    acc1[j] = fmaf(a.x, w2[(ci + 0) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(a.y, w2[(ci + 1) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(a.z, w2[(ci + 2) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(a.w, w2[(ci + 3) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(b.x, w0[(ci + 0) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(b.y, w0[(ci + 1) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(b.z, w0[(ci + 2) * COUT + j], acc1[j]);
+                    acc1[j] = fmaf(b.w, w0[(ci + 3) * COUT + j], acc1[j]);
+                }
+            }
+        }
+    }
+    const size_t vo = ((size_t)od * Ho + oh) * Wo + 2 * xi;
+    static_assert(CPT % 4 == 0, "CPT must be a multiple of 4");
+#pragma unroll
+    for (int j = 0; j < CPT; j += 4) {
+        const int co = co0 + j;
+        const size_t o = ((size_t)(co >> 3) * nvox + vo) * 8 + (co & 7);
+        const float4 s0 = *reinterpret_cast<const float4*>(skip + o);
+        const float4 s1 = *reinterpret_cast<const float4*>(skip + o + 8);
+        // skip + relu(bn(deconv(x)))   (models/mvsnet.py:69-71)
+        float4 r0, r1;
+        r0.x = fmaxf(acc0[j + 0], 0.f) + s0.x; r0.y = fmaxf(acc0[j + 1], 0.f) + s0.y;
+        r0.z = fmaxf(acc0[j + 2], 0.f) + s0.z; r0.w = fmaxf(acc0[j + 3], 0.f) + s0.w;
+        r1.x = fmaxf(acc1[j + 0], 0.f) + s1.x; r1.y = fmaxf(acc1[j + 1], 0.f) + s1.y;
+        r1.z = fmaxf(acc1[j + 2], 0.f) + s1.z; r1.w = fmaxf(acc1[j + 3], 0.f) + s1.w;
+        *reinterpret_cast<float4*>(y + o) = r0;
+        *reinterpret_cast<float4*>(y + o + 8) = r1;
+    }
+}
+
+template <int CIN, int COUT, int CPT>
+static int run_deconv(const void* x, const void* skip, void* y, const float* wgt, const float* bias,
+                      int Di, int Hi, int Wi, hipStream_t s) {
+    const size_t nthreads = (size_t)Di * Hi * Wi;
+    dim3 grid((unsigned)((nthreads + 255) / 256), COUT / CPT, 4);
+    deconv3d_direct_kernel<CIN, COUT, CPT><<<grid, 256, 0, s>>>(
+        static_cast<const float*>(x), wgt, bias, static_cast<const float*>(skip),
+        static_cast<float*>(y), Di, Hi, Wi);
+    return check_hip(hipGetLastError(), "deconv3d_direct launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// prob: Conv3d 8 -> 1 with bias, no BN / ReLU (models/mvsnet.py:62,72).  A thread produces 4
+// x-adjacent logits (one 16-byte store) from a 3 x 3 x 6 window of 8-channel voxels, so each
+// staged voxel feeds up to 3 outputs from registers: 54 loads per 4 outputs instead of 108.
+//   x [1][D][H][W][8] -> y [D][H][W]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ wgt,  // [27][8][1]
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, int D, int H, int W) {
+    const int W4 = W >> 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)D * H * W4) return;
+    const int x4 = (int)(t % W4), oy = (int)((t / W4) % H), oz = (int)(t / ((size_t)W4 * H));
+    const int ox = 4 * x4;
+    float acc[4];
+    const float bv = bias[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bv;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int iz = oz + kd - 1;
+        if (iz < 0 || iz >= D) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy + kh - 1;
+            if (iy < 0 || iy >= H) continue;
+            const float* row = x + (((size_t)iz * H + iy) * W) * 8;
+            const float* wk = wgt + (size_t)((kd * 3 + kh) * 3) * 8;  // [kw][ci]
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {  // input columns ox-1 .. ox+4
+                const int ix = ox + c - 1;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (ix >= 0 && ix < W) {
+                    a = *reinterpret_cast<const float4*>(row + (size_t)ix * 8);
+                    b = *reinterpret_cast<const float4*>(row + (size_t)ix * 8 + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kw = c - j;  // input column c feeds output j through tap kw
+                    if (kw < 0 || kw > 2) continue;
+                    const float* wv = wk + kw * 8;
+                    acc[j] = fmaf(a.x, wv[0], fmaf(a.y, wv[1], fmaf(a.z, wv[2], fmaf(a.w, wv[3], acc[j]))));
+                    acc[j] = fmaf(b.x, wv[4], fmaf(b.y, wv[5], fmaf(b.z, wv[6], fmaf(b.w, wv[7], acc[j]))));
+                }
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((size_t)oz * H + oy) * W + ox) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+static int run_prob(const void* x, void* y, const float* wgt, const float* bias, int D, int H, int W,
+                    hipStream_t s) {
+    const size_t nthreads = (size_t)D * H * (W >> 2);
+    prob_conv_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(
+        static_cast<const float*>(x), wgt, bias, static_cast<float*>(y), D, H, W);
+    return check_hip(hipGetLastError(), "prob_conv launch");
+}
+
 template <int CIN, int COUT, int CPT, int STRIDE, bool DECONV, bool RELU, bool SKIP>
 static int run_direct(const void* x, const void* skip, void* y, const float* wgt, const float* bias,
                       int Di, int Hi, int Wi, hipStream_t s) {
@@ -143,10 +296,12 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
         case 4: return run_direct<32, 32, 8, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 5: return run_direct<32, 64, 4, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 6: return run_direct<64, 64, 4, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 7: return run_direct<64, 32, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 8: return run_direct<32, 16, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 9: return run_direct<16, 8, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 10: return run_direct<8, 1, 1, 1, false, false, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 7: return run_deconv<64, 32, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 8: return run_deconv<32, 16, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 9: return run_deconv<16, 8, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 10:
+            if ((Wi & 3) == 0) return run_prob(x, y, wgt, bias, Di, Hi, Wi, s);
+            return run_direct<8, 1, 1, 1, false, false, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "unknown CostRegNet layer %d", layer);
     }
 }
