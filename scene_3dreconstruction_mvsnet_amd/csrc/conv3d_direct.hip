@@ -215,57 +215,59 @@ static int run_deconv(const void* x, const void* skip, void* y, const float* wgt
 }
 
 // ---------------------------------------------------------------------------------------------
-// prob: Conv3d 8 -> 1 with bias, no BN / ReLU (models/mvsnet.py:62,72).  A thread produces 4
-// x-adjacent logits (one 16-byte store) from a 3 x 3 x 6 window of 8-channel voxels, so each
-// staged voxel feeds up to 3 outputs from registers: 54 loads per 4 outputs instead of 108.
+// prob: Conv3d 8 -> 1 with bias, no BN / ReLU (models/mvsnet.py:62,72).  A thread produces the
+// logits of ZPT z-adjacent voxels at one (y, x): lanes stay on x-adjacent voxels (coalesced
+// 32-byte loads, 4-byte stores) while each staged voxel feeds up to 3 outputs from registers:
+// (ZPT+2)*9 voxel loads per ZPT outputs instead of 27 per output.
 //   x [1][D][H][W][8] -> y [D][H][W]
 // ---------------------------------------------------------------------------------------------
+constexpr int kProbZPT = 4;
+
 __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ wgt,  // [27][8][1]
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, int D, int H, int W) {
-    const int W4 = W >> 2;
+    const size_t hw = (size_t)H * W;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)D * H * W4) return;
-    const int x4 = (int)(t % W4), oy = (int)((t / W4) % H), oz = (int)(t / ((size_t)W4 * H));
-    const int ox = 4 * x4;
-    float acc[4];
+    const int nzb = (D + kProbZPT - 1) / kProbZPT;
+    if (t >= hw * nzb) return;
+    const int ox = (int)(t % W), oy = (int)((t / W) % H), oz0 = (int)(t / hw) * kProbZPT;
+    float acc[kProbZPT];
     const float bv = bias[0];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = bv;
-    for (int kd = 0; kd < 3; ++kd) {
-        const int iz = oz + kd - 1;
+    for (int j = 0; j < kProbZPT; ++j) acc[j] = bv;
+#pragma unroll
+    for (int c = 0; c < kProbZPT + 2; ++c) {  // input planes oz0-1 .. oz0+ZPT
+        const int iz = oz0 + c - 1;
         if (iz < 0 || iz >= D) continue;
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = oy + kh - 1;
             if (iy < 0 || iy >= H) continue;
-            const float* row = x + (((size_t)iz * H + iy) * W) * 8;
-            const float* wk = wgt + (size_t)((kd * 3 + kh) * 3) * 8;  // [kw][ci]
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox + kw - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float* xp = x + (((size_t)iz * H + iy) * W + ix) * 8;
+                const float4 a = *reinterpret_cast<const float4*>(xp);
+                const float4 b = *reinterpret_cast<const float4*>(xp + 4);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {  // input columns ox-1 .. ox+4
-                const int ix = ox + c - 1;
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                if (ix >= 0 && ix < W) {
-                    a = *reinterpret_cast<const float4*>(row + (size_t)ix * 8);
-                    b = *reinterpret_cast<const float4*>(row + (size_t)ix * 8 + 4);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kw = c - j;  // input column c feeds output j through tap kw
-                    if (kw < 0 || kw > 2) continue;
-                    const float* wv = wk + kw * 8;
+                for (int j = 0; j < kProbZPT; ++j) {
+                    const int kd = c - j;  // input plane c feeds output j through tap kd
+                    if (kd < 0 || kd > 2) continue;
+                    const float* wv = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * 8;
                     acc[j] = fmaf(a.x, wv[0], fmaf(a.y, wv[1], fmaf(a.z, wv[2], fmaf(a.w, wv[3], acc[j]))));
                     acc[j] = fmaf(b.x, wv[4], fmaf(b.y, wv[5], fmaf(b.z, wv[6], fmaf(b.w, wv[7], acc[j]))));
                 }
             }
         }
     }
-    *reinterpret_cast<float4*>(y + ((size_t)oz * H + oy) * W + ox) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int j = 0; j < kProbZPT; ++j)
+        if (oz0 + j < D) y[(size_t)(oz0 + j) * hw + (size_t)oy * W + ox] = acc[j];
 }
 
 static int run_prob(const void* x, void* y, const float* wgt, const float* bias, int D, int H, int W,
                     hipStream_t s) {
-    const size_t nthreads = (size_t)D * H * (W >> 2);
+    const size_t nthreads = (size_t)H * W * ((D + kProbZPT - 1) / kProbZPT);
     prob_conv_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(
         static_cast<const float*>(x), wgt, bias, static_cast<float*>(y), D, H, W);
     return check_hip(hipGetLastError(), "prob_conv launch");
@@ -296,12 +298,11 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
         case 4: return run_direct<32, 32, 8, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 5: return run_direct<32, 64, 4, 2, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 6: return run_direct<64, 64, 4, 1, false, true, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 7: return run_deconv<64, 32, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
-        case 8: return run_deconv<32, 16, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 7: return run_direct<64, 32, 8, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+        case 8: return run_direct<32, 16, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 9: return run_deconv<16, 8, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 10:
-            if ((Wi & 3) == 0) return run_prob(x, y, wgt, bias, Di, Hi, Wi, s);
-            return run_direct<8, 1, 1, 1, false, false, false>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
+            return run_prob(x, y, wgt, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "unknown CostRegNet layer %d", layer);
     }
 }
