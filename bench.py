@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from scene_3dreconstruction_mvsnet_amd import _lib, synthetic  # noqa: E402
+from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
@@ -102,7 +102,6 @@ def main():
     wss = [_lib.alloc_workspace(N, 32, D, h, w, dev) for _ in range(S)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
-    gathered = torch.empty((world * K, 2, h, w), dtype=torch.float32, device=dev) if world > 1 else None
 
     stage_names = ["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"]
     n_ev = len(stage_names) + 1
@@ -151,7 +150,9 @@ def main():
     for st in streams[1:]:
         streams[0].wait_stream(st)
     if world > 1:
-        dist.all_gather_into_tensor(gathered, out)  # the final gather (RCCL over xGMI)
+        # the final gather (RCCL over xGMI): rank r owns units r::world of the world*K maps
+        gathered = sharding.gather_maps(out, world * K, rank, world)
+        assert gathered.shape[0] == world * K
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
