@@ -100,6 +100,8 @@ int launch_nchw_to_c8(const float* in, float* out, int N, int C, int h, int w, h
 int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s);
 int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s);
+int launch_warp_variance_lds(const float* feats_p, const float* rt, const float* dv, void* var, int N,
+                             int D, int h, int w, hipStream_t s);
 int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,
                      int h, int w, hipStream_t s);
 int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* blob,

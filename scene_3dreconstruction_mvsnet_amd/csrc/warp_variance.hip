@@ -13,6 +13,8 @@
 // (= one K-chunk of 8 input channels) at a time.
 //
 // HBM-bound: algorithmic bytes per map = N*32*h*w*4 (features) + 32*D*h*w*es (volume write).
+#include <cstdlib>
+
 #include "mvs_internal.h"
 
 namespace mvs {
@@ -240,6 +242,13 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
                          int D, int h, int w, int dtype, hipStream_t s) {
     if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "warp_variance: dtype %d not implemented", dtype);
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
+    // default: LDS-staged kernel (warp_variance_lds.hip); MVS_WARP_GLOBAL=1 keeps the L1-gather
+    // version for A/B runs
+    static const bool force_global = [] {
+        const char* e = getenv("MVS_WARP_GLOBAL");
+        return e && e[0] == '1';
+    }();
+    if (!force_global) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
     dim3 grid((h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
     warp_variance_kernel<<<grid, 256, 0, s>>>(feats_p, rt, dv, static_cast<float*>(var), N, D, h, w);
     return check_hip(hipGetLastError(), "warp_variance launch");

@@ -1,0 +1,258 @@
+// warp_variance_lds.hip -- LDS-staged homography warp + variance cost volume (gfx950).
+//
+// Same contract as warp_variance_kernel (warp_variance.hip; reference models/module.py:96-139 and
+// models/mvsnet.py:145-177) but the bilinear gathers are served from LDS instead of L1: the
+// global-gather version is bound by the CU's 64 B/clk vector-L1 path (every source texel is
+// fetched ~4x by neighbouring pixels and once more per depth), LDS delivers 256 B/clk.
+//
+// Block = 16 x 8 reference pixels x 4 depth planes x 2 channel planes (16 channels).
+//   thread (pixel, e): depth parity e -> it samples depths d0+e and d0+2+e for 8+8 channels,
+//   so sampling coordinates are computed exactly once per (pixel, depth, view) in the block.
+// Per source view:
+//   1. wave 0 projects the 8 corners of the (tile x depth-slab) box -- the map is linear-
+//      fractional in x, y and d separately, so its extremes sit on the box vertices -- and
+//      reduces them with wavefront shuffles to the source bounding box (all views at once,
+//      8 lanes per view);
+//   2. the block stages that box of the view's two channel planes into LDS (row segments are
+//      contiguous in the C8-planar feature layout: coalesced);
+//   3. every thread takes its 4 taps x 16 channels from LDS and accumulates sum / sum of squares
+//      in registers across views.
+// Views whose box does not fit (strong rotation/zoom, points behind the camera) fall back to
+// global gathers for that view only, with identical arithmetic.
+#include "mvs_internal.h"
+
+namespace mvs {
+
+namespace wl {
+constexpr int TW = 16, TH = 8;     // reference-pixel tile
+constexpr int DS = 4;              // depth planes per block
+constexpr int MAX_BW = 32;         // widest stageable source box (texels)
+constexpr int MAX_TEXELS = 512;    // per channel plane: 2 planes x 512 x 32 B = 32 KiB LDS
+constexpr int MAX_VIEWS = 64;
+}  // namespace wl
+
+struct Samp {
+    int o00, o01, o10, o11;        // texel offsets (clamped into the window)
+    float w00, w01, w10, w11;      // bilinear weights; 0 for taps outside the image; NaN if the
+                                   // sampling coordinate is not finite (torch CPU grid_sample)
+};
+
+// Window = [x_lo, x_lo+bw) x [y_lo, y_lo+bh) inside the image; offsets are relative to it.
+__device__ __forceinline__ Samp make_samp(float qx, float qy, float qz, float tx, float ty, float tz,
+                                          float d, float sx, float sy, int h, int w, int x_lo,
+                                          int y_lo, int bw, int bh) {
+    const float X = fmaf(qx, d, tx), Y = fmaf(qy, d, ty), Z = fmaf(qz, d, tz);
+    const float ix = (X / Z) * sx - 0.5f;   // px*W/(W-1) - 0.5      (module.py:129-136)
+    const float iy = (Y / Z) * sy - 0.5f;
+    const bool bad = !(fabsf(ix) <= 3.0e38f) || !(fabsf(iy) <= 3.0e38f);
+    const float cx = fminf(fmaxf(ix, -2.0f), (float)w + 1.0f);
+    const float cy = fminf(fmaxf(iy, -2.0f), (float)h + 1.0f);
+    const float fx0 = floorf(cx), fy0 = floorf(cy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float ax = cx - fx0, ay = cy - fy0;
+    const bool in = (cx == ix) && (cy == iy);
+    const bool x0ok = in && x0 >= 0 && x0 < w, x1ok = in && x0 + 1 >= 0 && x0 + 1 < w;
+    const bool y0ok = y0 >= 0 && y0 < h, y1ok = y0 + 1 >= 0 && y0 + 1 < h;
+    Samp s;
+    s.w00 = (x0ok && y0ok) ? (1.0f - ax) * (1.0f - ay) : 0.0f;
+    s.w01 = (x1ok && y0ok) ? ax * (1.0f - ay) : 0.0f;
+    s.w10 = (x0ok && y1ok) ? (1.0f - ax) * ay : 0.0f;
+    s.w11 = (x1ok && y1ok) ? ax * ay : 0.0f;
+    if (bad) { s.w00 = NAN; s.w01 = NAN; s.w10 = NAN; s.w11 = NAN; }
+    const int xa = min(max(x0 - x_lo, 0), bw - 1), xb = min(max(x0 + 1 - x_lo, 0), bw - 1);
+    const int ya = min(max(y0 - y_lo, 0), bh - 1), yb = min(max(y0 + 1 - y_lo, 0), bh - 1);
+    s.o00 = ya * bw + xa; s.o01 = ya * bw + xb;
+    s.o10 = yb * bw + xa; s.o11 = yb * bw + xb;
+    return s;
+}
+
+// 8 channels of one plane: base points at [texel][8] floats
+__device__ __forceinline__ void sample8(const float* __restrict__ base, const Samp& s, float4& lo,
+                                        float4& hi) {
+    const float4 a0 = *reinterpret_cast<const float4*>(base + s.o00 * 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(base + s.o00 * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(base + s.o01 * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(base + s.o01 * 8 + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(base + s.o10 * 8);
+    const float4 c1 = *reinterpret_cast<const float4*>(base + s.o10 * 8 + 4);
+    const float4 e0 = *reinterpret_cast<const float4*>(base + s.o11 * 8);
+    const float4 e1 = *reinterpret_cast<const float4*>(base + s.o11 * 8 + 4);
+    lo.x = fmaf(a0.x, s.w00, fmaf(b0.x, s.w01, fmaf(c0.x, s.w10, e0.x * s.w11)));
+    lo.y = fmaf(a0.y, s.w00, fmaf(b0.y, s.w01, fmaf(c0.y, s.w10, e0.y * s.w11)));
+    lo.z = fmaf(a0.z, s.w00, fmaf(b0.z, s.w01, fmaf(c0.z, s.w10, e0.z * s.w11)));
+    lo.w = fmaf(a0.w, s.w00, fmaf(b0.w, s.w01, fmaf(c0.w, s.w10, e0.w * s.w11)));
+    hi.x = fmaf(a1.x, s.w00, fmaf(b1.x, s.w01, fmaf(c1.x, s.w10, e1.x * s.w11)));
+    hi.y = fmaf(a1.y, s.w00, fmaf(b1.y, s.w01, fmaf(c1.y, s.w10, e1.y * s.w11)));
+    hi.z = fmaf(a1.z, s.w00, fmaf(b1.z, s.w01, fmaf(c1.z, s.w10, e1.z * s.w11)));
+    hi.w = fmaf(a1.w, s.w00, fmaf(b1.w, s.w01, fmaf(c1.w, s.w10, e1.w * s.w11)));
+}
+
+__device__ __forceinline__ void accum(float4& S, float4& Q, const float4& v) {
+    S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
+    Q.x = fmaf(v.x, v.x, Q.x); Q.y = fmaf(v.y, v.y, Q.y);
+    Q.z = fmaf(v.z, v.z, Q.z); Q.w = fmaf(v.w, v.w, Q.w);
+}
+
+__device__ __forceinline__ float4 variance4(const float4& S, const float4& Q, float inv_n) {
+    // var = Q/N - (S/N)^2        (models/mvsnet.py:177)
+    float4 o;
+    float m;
+    m = S.x * inv_n; o.x = fmaf(-m, m, Q.x * inv_n);
+    m = S.y * inv_n; o.y = fmaf(-m, m, Q.y * inv_n);
+    m = S.z * inv_n; o.z = fmaf(-m, m, Q.z * inv_n);
+    m = S.w * inv_n; o.w = fmaf(-m, m, Q.w * inv_n);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void warp_variance_lds_kernel(const float* __restrict__ feats_p,
+                                                                const float* __restrict__ rt,
+                                                                const float* __restrict__ dv,
+                                                                float* __restrict__ var, int N,
+                                                                int D, int h, int w) {
+    using namespace wl;
+    __shared__ __attribute__((aligned(16))) float tile[2 * MAX_TEXELS * 8];  // 32 KiB
+    __shared__ int4 bbox[MAX_VIEWS];  // x_lo, y_lo, bw, bh (bh < 0: fall back to global gathers)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = tid & 1, pix = tid >> 1;
+    const int tilesx = (w + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tilesx) * TW, ty0 = (blockIdx.x / tilesx) * TH;
+    const int x = tx0 + (pix & (TW - 1)), y = ty0 + (pix >> 4);
+    const int d0 = blockIdx.y * DS;
+    const int pp = blockIdx.z;  // channel planes 2pp, 2pp+1
+    const int hw = h * w;
+    const bool active = x < w && y < h;
+    const int xs = min(x, w - 1), ys = min(y, h - 1);  // clamped coordinates keep idle lanes harmless
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const size_t plane_stride = (size_t)N * hw * 8;  // floats between channel planes of the features
+    const float* fplane = feats_p + (size_t)(2 * pp) * plane_stride;
+
+    // ---- source bounding boxes of all views: 8 lanes per view, shuffle min/max reduction ----
+    if (wave == 0) {
+        const int c = lane & 7;
+        const float cxp = (float)((c & 1) ? min(tx0 + TW - 1, w - 1) : tx0);
+        const float cyp = (float)((c & 2) ? min(ty0 + TH - 1, h - 1) : ty0);
+        const float cd = dv[(c & 4) ? min(d0 + DS - 1, D - 1) : d0];
+        for (int v0 = 1; v0 < N; v0 += 8) {
+            const int v = v0 + (lane >> 3);
+            float ix = 0.f, iy = 0.f, Z = 1.f;
+            if (v < N) {
+                const float* r = rt + (size_t)(v - 1) * 12;
+                const float X = fmaf(fmaf(r[0], cxp, fmaf(r[1], cyp, r[2])), cd, r[9]);
+                const float Y = fmaf(fmaf(r[3], cxp, fmaf(r[4], cyp, r[5])), cd, r[10]);
+                Z = fmaf(fmaf(r[6], cxp, fmaf(r[7], cyp, r[8])), cd, r[11]);
+                ix = (X / Z) * sx - 0.5f;
+                iy = (Y / Z) * sy - 0.5f;
+            }
+            float xmin = ix, xmax = ix, ymin = iy, ymax = iy, zmin = Z;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                xmin = fminf(xmin, __shfl_xor(xmin, m)); xmax = fmaxf(xmax, __shfl_xor(xmax, m));
+                ymin = fminf(ymin, __shfl_xor(ymin, m)); ymax = fmaxf(ymax, __shfl_xor(ymax, m));
+                zmin = fminf(zmin, __shfl_xor(zmin, m));
+            }
+            if (c == 0 && v < N) {
+                // fminf/fmaxf drop NaNs, so test finiteness on the sum of the extremes
+                const bool ok = zmin > 1e-20f && fabsf(xmin) + fabsf(xmax) + fabsf(ymin) + fabsf(ymax) < 1.0e9f;
+                int x_lo = 0, y_lo = 0, x_hi = w - 1, y_hi = h - 1;
+                if (ok) {
+                    x_lo = (int)floorf(fminf(fmaxf(xmin, -4.f), (float)w + 4.f)) - 1;
+                    x_hi = (int)floorf(fminf(fmaxf(xmax, -4.f), (float)w + 4.f)) + 2;
+                    y_lo = (int)floorf(fminf(fmaxf(ymin, -4.f), (float)h + 4.f)) - 1;
+                    y_hi = (int)floorf(fminf(fmaxf(ymax, -4.f), (float)h + 4.f)) + 2;
+                    x_lo = min(max(x_lo, 0), w - 2); x_hi = min(max(x_hi, x_lo + 1), w - 1);
+                    y_lo = min(max(y_lo, 0), h - 2); y_hi = min(max(y_hi, y_lo + 1), h - 1);
+                }
+                const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+                const bool fits = ok && bw <= MAX_BW && bw * bh <= MAX_TEXELS;
+                bbox[v - 1] = fits ? make_int4(x_lo, y_lo, bw, bh) : make_int4(0, 0, w, -h);
+            }
+        }
+    }
+
+    // ---- accumulators: depth slot j -> depth d0 + 2j + e; planes 2pp, 2pp+1; 8 channels each ----
+    float4 S[2][2][2], Q[2][2][2];  // [j][plane][lo/hi]
+    {
+        const float* rp = fplane + ((size_t)ys * w + xs) * 8;  // view 0 = reference feature
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float4 lo = *reinterpret_cast<const float4*>(rp + pl * plane_stride);
+            const float4 hi = *reinterpret_cast<const float4*>(rp + pl * plane_stride + 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                S[j][pl][0] = lo; S[j][pl][1] = hi;
+                Q[j][pl][0] = make_float4(lo.x * lo.x, lo.y * lo.y, lo.z * lo.z, lo.w * lo.w);
+                Q[j][pl][1] = make_float4(hi.x * hi.x, hi.y * hi.y, hi.z * hi.z, hi.w * hi.w);
+            }
+        }
+    }
+    const float fx = (float)xs, fy = (float)ys;
+    float depth[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) depth[j] = dv[min(d0 + 2 * j + e, D - 1)];
+    __syncthreads();  // bbox[] visible
+
+    for (int v = 1; v < N; ++v) {
+        const int4 bb = bbox[v - 1];
+        const bool use_lds = bb.w > 0;  // block-uniform
+        const int bw = bb.z, bh = use_lds ? bb.w : -bb.w;
+        const float* vplane = fplane + (size_t)v * hw * 8;
+        if (use_lds) {
+            __syncthreads();  // previous view's samples are done with the tile
+            // stage rows: wave-strided over (plane, row); lanes cover the row's 2*bw 16-byte pieces
+            const int tx = lane >> 1, hq = lane & 1;
+            for (int row = wave; row < 2 * bh; row += 4) {
+                const int pl = row >= bh ? 1 : 0, ty = row - pl * bh;
+                if (tx < bw) {
+                    const float4 val = *reinterpret_cast<const float4*>(
+                        vplane + pl * plane_stride + ((size_t)(bb.y + ty) * w + bb.x + tx) * 8 + hq * 4);
+                    *reinterpret_cast<float4*>(tile + ((pl * bh + ty) * bw + tx) * 8 + hq * 4) = val;
+                }
+            }
+            __syncthreads();
+        }
+        const float* r = rt + (size_t)(v - 1) * 12;
+        const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+        const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+        const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Samp s = make_samp(qx, qy, qz, r[9], r[10], r[11], depth[j], sx, sy, h, w, bb.x,
+                                     bb.y, bw, bh);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                float4 lo, hi;
+                if (use_lds) sample8(tile + pl * bh * bw * 8, s, lo, hi);
+                else sample8(vplane + pl * plane_stride, s, lo, hi);
+                accum(S[j][pl][0], Q[j][pl][0], lo);
+                accum(S[j][pl][1], Q[j][pl][1], hi);
+            }
+        }
+    }
+
+    if (!active) return;
+    const float inv_n = 1.0f / (float)N;
+    const size_t V0 = (size_t)D * hw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int d = d0 + 2 * j + e;
+        if (d >= D) continue;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            float* o = var + ((size_t)(2 * pp + pl) * V0 + (size_t)d * hw + (size_t)y * w + x) * 8;
+            *reinterpret_cast<float4*>(o) = variance4(S[j][pl][0], Q[j][pl][0], inv_n);
+            *reinterpret_cast<float4*>(o + 4) = variance4(S[j][pl][1], Q[j][pl][1], inv_n);
+        }
+    }
+}
+
+int launch_warp_variance_lds(const float* feats_p, const float* rt, const float* dv, void* var, int N,
+                             int D, int h, int w, hipStream_t s) {
+    using namespace wl;
+    if (N > MAX_VIEWS) return fail(MVS_ERR_BAD_SHAPE, "warp_variance_lds: N=%d > %d", N, MAX_VIEWS);
+    dim3 grid(((w + TW - 1) / TW) * ((h + TH - 1) / TH), (D + DS - 1) / DS, 2);
+    warp_variance_lds_kernel<<<grid, 256, 0, s>>>(feats_p, rt, dv, static_cast<float*>(var), N, D, h, w);
+    return check_hip(hipGetLastError(), "warp_variance_lds launch");
+}
+
+}  // namespace mvs
