@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "mvs_internal.h"
+#include "warp_common.h"
 
 namespace mvs {
 
@@ -104,58 +105,6 @@ int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sampling coordinate of reference pixel (x,y) at depth d in a source view.
-//   p = rot*(x,y,1)*d + trans ; px = p.x/p.z ; normalise by (W-1)/2 then grid_sample's
-//   align_corners=False un-normalisation  =>  ix = px*W/(W-1) - 0.5   (module.py:125-136)
-// ---------------------------------------------------------------------------------------------
-struct Tap {
-    int off;        // element offset of the (y0,x0) tap in an [h][w][...] map, in pixels
-    float w00, w01, w10, w11;  // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 when out of bounds
-    bool nan;       // non-finite coordinate -> NaN output (torch CPU grid_sample)
-};
-
-__device__ __forceinline__ Tap make_tap(float qx, float qy, float qz, float tx, float ty, float tz,
-                                        float d, float sx, float sy, int h, int w) {
-    const float X = fmaf(qx, d, tx), Y = fmaf(qy, d, ty), Z = fmaf(qz, d, tz);
-    const float ix = (X / Z) * sx - 0.5f;
-    const float iy = (Y / Z) * sy - 0.5f;
-    Tap t;
-    t.nan = !(fabsf(ix) <= 3.0e38f) || !(fabsf(iy) <= 3.0e38f);
-    const float cx = fminf(fmaxf(ix, -2.0f), (float)w + 1.0f);  // clamp keeps int casts defined;
-    const float cy = fminf(fmaxf(iy, -2.0f), (float)h + 1.0f);  // clamped taps are out of bounds
-    const float fx0 = floorf(cx), fy0 = floorf(cy);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float ax = cx - fx0, ay = cy - fy0;
-    const bool in = (cx == ix) && (cy == iy);
-    const bool x0ok = in && x0 >= 0 && x0 < w, x1ok = in && x0 + 1 >= 0 && x0 + 1 < w;
-    const bool y0ok = y0 >= 0 && y0 < h, y1ok = y0 + 1 >= 0 && y0 + 1 < h;
-    t.w00 = (x0ok && y0ok) ? (1.0f - ax) * (1.0f - ay) : 0.0f;
-    t.w01 = (x1ok && y0ok) ? ax * (1.0f - ay) : 0.0f;
-    t.w10 = (x0ok && y1ok) ? (1.0f - ax) * ay : 0.0f;
-    t.w11 = (x1ok && y1ok) ? ax * ay : 0.0f;
-    // clamp the base so that all four addresses stay inside the map; weights are already zero
-    // for the taps that were moved
-    const int xb = min(max(x0, 0), w - 2), yb = min(max(y0, 0), h - 2);
-    if (xb != x0 || yb != y0) {
-        // re-associate the weights with the clamped 2x2 block
-        const float a00 = t.w00, a01 = t.w01, a10 = t.w10, a11 = t.w11;
-        float b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
-        auto put = [&](int yy, int xx, float wv) {
-            if (wv == 0.0f) return;
-            const int ry = yy - yb, rx = xx - xb;  // in {0,1} whenever wv != 0
-            if (ry == 0 && rx == 0) b00 = wv;
-            else if (ry == 0 && rx == 1) b01 = wv;
-            else if (ry == 1 && rx == 0) b10 = wv;
-            else b11 = wv;
-        };
-        put(y0, x0, a00); put(y0, x0 + 1, a01); put(y0 + 1, x0, a10); put(y0 + 1, x0 + 1, a11);
-        t.w00 = b00; t.w01 = b01; t.w10 = b10; t.w11 = b11;
-    }
-    t.off = yb * w + xb;
-    return t;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Fused warp + variance.  Thread = (pixel, half): it owns channels {8*pl + 4*half .. +3} of its
 // pixel for all four channel planes pl, so the sampling coordinates of a (pixel, depth, view)
 // are computed once and reused for 16 channels.  A wave covers 32 consecutive pixels; each of
@@ -197,22 +146,20 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
             Q[pl] = make_float4(ref[pl].x * ref[pl].x, ref[pl].y * ref[pl].y, ref[pl].z * ref[pl].z,
                                 ref[pl].w * ref[pl].w);
         }
-        bool any_nan = false;
         for (int v = 1; v < N; ++v) {
             const float* r = rt + (size_t)(v - 1) * 12;
             const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
             const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
             const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
-            const Tap t = make_tap(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w);
-            any_nan |= t.nan;
-            const float* f0 = feats_p + ((size_t)v * hw + t.off) * 8 + 4 * half;
+            const Samp t = make_samp(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w, 0, 0, w, h);
+            const float* f0 = feats_p + (size_t)v * hw * 8 + 4 * half;
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) {
                 const float* f = f0 + pl * plane_stride;
-                const float4 a = *reinterpret_cast<const float4*>(f);
-                const float4 b = *reinterpret_cast<const float4*>(f + 8);
-                const float4 c = *reinterpret_cast<const float4*>(f + (size_t)w * 8);
-                const float4 e = *reinterpret_cast<const float4*>(f + (size_t)w * 8 + 8);
+                const float4 a = *reinterpret_cast<const float4*>(f + (size_t)t.o00 * 8);
+                const float4 b = *reinterpret_cast<const float4*>(f + (size_t)t.o01 * 8);
+                const float4 c = *reinterpret_cast<const float4*>(f + (size_t)t.o10 * 8);
+                const float4 e = *reinterpret_cast<const float4*>(f + (size_t)t.o11 * 8);
                 float4 wv;
                 wv.x = fmaf(a.x, t.w00, fmaf(b.x, t.w01, fmaf(c.x, t.w10, e.x * t.w11)));
                 wv.y = fmaf(a.y, t.w00, fmaf(b.y, t.w01, fmaf(c.y, t.w10, e.y * t.w11)));
@@ -232,7 +179,6 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
             m = S[pl].y * inv_n; o.y = fmaf(-m, m, Q[pl].y * inv_n);
             m = S[pl].z * inv_n; o.z = fmaf(-m, m, Q[pl].z * inv_n);
             m = S[pl].w * inv_n; o.w = fmaf(-m, m, Q[pl].w * inv_n);
-            if (any_nan) o = make_float4(NAN, NAN, NAN, NAN);
             *reinterpret_cast<float4*>(var + ((size_t)pl * V0 + (size_t)d * hw + p) * 8 + 4 * half) = o;
         }
     }
@@ -242,13 +188,13 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
                          int D, int h, int w, int dtype, hipStream_t s) {
     if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "warp_variance: dtype %d not implemented", dtype);
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
-    // default: LDS-staged kernel (warp_variance_lds.hip); MVS_WARP_GLOBAL=1 keeps the L1-gather
-    // version for A/B runs
-    static const bool force_global = [] {
-        const char* e = getenv("MVS_WARP_GLOBAL");
+    // MVS_WARP_LDS=1 selects the LDS-staged kernel (warp_variance_lds.hip); the L1-gather kernel
+    // below is the default: it is the faster of the two on MI355X so far.
+    static const bool use_lds = [] {
+        const char* e = getenv("MVS_WARP_LDS");
         return e && e[0] == '1';
     }();
-    if (!force_global) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
+    if (use_lds && N <= 64) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
     dim3 grid((h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
     warp_variance_kernel<<<grid, 256, 0, s>>>(feats_p, rt, dv, static_cast<float*>(var), N, D, h, w);
     return check_hip(hipGetLastError(), "warp_variance launch");
@@ -272,12 +218,11 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const float* __restrict_
     const float qx = fmaf(rt[0], fx, fmaf(rt[1], fy, rt[2]));
     const float qy = fmaf(rt[3], fx, fmaf(rt[4], fy, rt[5]));
     const float qz = fmaf(rt[6], fx, fmaf(rt[7], fy, rt[8]));
-    const Tap t = make_tap(qx, qy, qz, rt[9], rt[10], rt[11], dv[d], sx, sy, h, w);
+    const Samp t = make_samp(qx, qy, qz, rt[9], rt[10], rt[11], dv[d], sx, sy, h, w, 0, 0, w, h);
     for (int c = 0; c < C; ++c) {
-        const float* f = fea + (size_t)c * hw + t.off;
-        float v = fmaf(f[0], t.w00, fmaf(f[1], t.w01, fmaf(f[w], t.w10, f[w + 1] * t.w11)));
-        if (t.nan) v = NAN;
-        out[(size_t)c * D * hw + i] = v;
+        const float* f = fea + (size_t)c * hw;
+        out[(size_t)c * D * hw + i] =
+            fmaf(f[t.o00], t.w00, fmaf(f[t.o01], t.w01, fmaf(f[t.o10], t.w10, f[t.o11] * t.w11)));
     }
 }
 
