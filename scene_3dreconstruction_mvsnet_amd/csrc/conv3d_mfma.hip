@@ -79,31 +79,40 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline over the 4 K-chunks: the global loads of chunk c+1's halo tile are issued
+    // before chunk c's MFMAs and written to LDS after them; chunk c+1's B panel is fetched while
+    // the block drains through the barriers.
+    f32x4 breg[KS];
+    f32x4 stg[PIECES_PER_THREAD];
+#define MVS_LOAD_B(C)                                                                         \
+    {                                                                                         \
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) + (size_t)(C) * KS * 64 + lane; \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) breg[ks] = bsrc[ks * 64];           \
+    }
+#define MVS_LOAD_A(C)                                                                         \
+    {                                                                                         \
+        const float* plane = x + (size_t)(C) * V * 8;                                         \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
+            stg[i] = (goff[i] >= 0) ? *reinterpret_cast<const f32x4*>(plane + goff[i])        \
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};                            \
+    }
+#define MVS_STORE_A()                                                                         \
+    {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
+            if (loff[i] >= 0) *reinterpret_cast<f32x4*>(tile + loff[i]) = stg[i];             \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+    const float* abase = tile + lane_off;
+#pragma unroll 1
     for (int c = 0; c < 4; ++c) {
-        // B panel of this chunk -> registers (coalesced 1 KiB per wave-load)
-        f32x4 breg[KS];
-        const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) + (size_t)c * KS * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) breg[ks] = bsrc[ks * 64];
-
-        // stage the halo tile of input plane c
-        const float* plane = x + (size_t)c * V * 8;
-        f32x4 stg[PIECES_PER_THREAD];
-#pragma unroll
-        for (int i = 0; i < PIECES_PER_THREAD; ++i)
-            stg[i] = (goff[i] >= 0) ? *reinterpret_cast<const f32x4*>(plane + goff[i])
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
-        __syncthreads();  // every wave is done reading the previous chunk's tile
-#pragma unroll
-        for (int i = 0; i < PIECES_PER_THREAD; ++i)
-            if (loff[i] >= 0) *reinterpret_cast<f32x4*>(tile + loff[i]) = stg[i];
-        __syncthreads();
-
-        const float* abase = tile + lane_off;
+        if (c < 3) MVS_LOAD_A(c + 1)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int tap0 = 2 * ks;  // taps (kz, ky, kx') with kx' = tap % 4
             const int kz = tap0 / 12, ky = (tap0 / 4) % 3, kx0 = tap0 % 4;
             const int koff = ((kz * HY + ky) * HX + kx0) * VS;
@@ -121,7 +130,16 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
         }
+        if (c < 3) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();  // every wave is done reading chunk c's tile
+            MVS_STORE_A()
+            __syncthreads();
+        }
     }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
 
     // epilogue: D layout col n = lane&15 = (j, co), row m = 4*(lane>>4) + e = pair index
     const int n = lane & 15, jj = n >> 3, co = n & 7;
