@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
     const size_t V = (size_t)D * H * W;
 
-    // fill bookkeeping: piece -> (halo voxel, half); global offset or -1 when outside the volume
+    // fill bookkeeping: piece -> (halo voxel, half).  Loads are unconditional (out-of-volume
+    // pieces read offset 0 and are zeroed by `inside` when written to LDS): a predicated load
+    // would make the compiler fall back to s_waitcnt vmcnt(0) and serialise the pipeline below.
     int goff[PIECES_PER_THREAD];
     int loff[PIECES_PER_THREAD];
+    unsigned inside = 0;
 #pragma unroll
     for (int i = 0; i < PIECES_PER_THREAD; ++i) {
         const int p = tid + i * 256;
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
         const int hy = t % HY, hz = t / HY;
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8 + half * 4) : -1;
+        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8 + half * 4) : 0;
+        inside |= ok ? (1u << i) : 0u;
         loff[i] = (p < NPIECE) ? v * VS + half * 4 : -1;
     }
 
@@ -93,13 +97,14 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
     {                                                                                         \
         const float* plane = x + (size_t)(C) * V * 8;                                         \
         _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
-            stg[i] = (goff[i] >= 0) ? *reinterpret_cast<const f32x4*>(plane + goff[i])        \
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};                            \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                        \
     }
 #define MVS_STORE_A()                                                                         \
     {                                                                                         \
         _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
-            if (loff[i] >= 0) *reinterpret_cast<f32x4*>(tile + loff[i]) = stg[i];             \
+            if (loff[i] >= 0)                                                                 \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                   \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};              \
     }
 
     MVS_LOAD_B(0)
