@@ -20,6 +20,8 @@
 // lane, pre-packed in lane order by mvs_pack_weights) is held in registers (weight-stationary)
 // while the wave streams its 4 M-tiles' A fragments from LDS: one ds_read_b128 feeds 4 MFMAs.
 // LDS use is 65 KB per block -> 2 blocks per CU, so one block's fill overlaps the other's MFMAs.
+#include <cstdlib>
+
 #include "mvs_internal.h"
 
 namespace mvs {
@@ -165,6 +167,174 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 8-wave variant: same tile, staging and GEMM as above, but the block has 512 threads and the K
+// range of every chunk is split between two wave groups (waves 0-3: k-steps 0..8, waves 4-7:
+// k-steps 9..17) that work on the same 16 M-tiles; the partial accumulators of the second group
+// are added through LDS at the end.  Halving the per-wave B panel (36 VGPRs) brings the kernel
+// under 128 VGPRs, so 2 blocks x 8 waves = 4 waves per SIMD keep the MFMA pipe fed while other
+// waves stage, wait at barriers or run the epilogue.
+// ---------------------------------------------------------------------------------------------
+namespace c0 {
+constexpr int KSH = KS / 2;                               // k-steps per wave group (9)
+constexpr int PIECES_PER_THREAD8 = (NPIECE + 511) / 512;  // 6
+}  // namespace c0
+
+__global__ __launch_bounds__(512, 4) void conv0_pair_mfma8_kernel(
+    const float* __restrict__ x, const float* __restrict__ bp, const float* __restrict__ bias,
+    float* __restrict__ y, int D, int H, int W) {
+    using namespace c0;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = wave >> 2, mg = wave & 3;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const size_t V = (size_t)D * H * W;
+
+    int goff[PIECES_PER_THREAD8];
+    int loff[PIECES_PER_THREAD8];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_THREAD8; ++i) {
+        const int p = tid + i * 512;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, t = v / HX;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8 + half * 4) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (p < NPIECE) ? v * VS + half * 4 : -1;
+    }
+
+    const int r = lane & 15, g = lane >> 4;
+    const int zt = mg >> 1, yt0 = 4 * (mg & 1);
+    const int lane_off = ((zt * HY + yt0) * HX + 2 * r + (g >> 1)) * VS + (g & 1) * 4;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 breg[KSH];
+    f32x4 stg[PIECES_PER_THREAD8];
+#define MVS_LOAD_B(C)                                                                              \
+    {                                                                                              \
+        const f32x4* bsrc =                                                                        \
+            reinterpret_cast<const f32x4*>(bp) + ((size_t)(C) * KS + kh * KSH) * 64 + lane;        \
+        _Pragma("unroll") for (int ks = 0; ks < KSH; ++ks) breg[ks] = bsrc[ks * 64];               \
+    }
+#define MVS_LOAD_A(C)                                                                              \
+    {                                                                                              \
+        const float* plane = x + (size_t)(C) * V * 8;                                              \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD8; ++i)                             \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                             \
+    }
+#define MVS_STORE_A()                                                                              \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD8; ++i)                             \
+            if (loff[i] >= 0)                                                                      \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                        \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};                   \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+    const float* abase = tile + lane_off;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c < 3) MVS_LOAD_A(c + 1)
+        if (kh == 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) {
+                const int tap0 = 2 * ks;
+                const int kz = tap0 / 12, ky = (tap0 / 4) % 3, kx0 = tap0 % 4;
+                const int koff = ((kz * HY + ky) * HX + kx0) * VS;
+                f32x4 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(abase + koff + i * HX * VS);
+                const f32x4 bq = breg[ks];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) {
+                const int tap0 = 2 * (ks + KSH);
+                const int kz = tap0 / 12, ky = (tap0 / 4) % 3, kx0 = tap0 % 4;
+                const int koff = ((kz * HY + ky) * HX + kx0) * VS;
+                f32x4 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(abase + koff + i * HX * VS);
+                const f32x4 bq = breg[ks];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
+            }
+        }
+        if (c < 3) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    // cross-group reduction through LDS (the halo tile is dead now): group 1 publishes its
+    // partial accumulators, group 0 adds them and runs the epilogue
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(tile);
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(mg * 4 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 o = red[(mg * 4 + i) * 64 + lane];
+        acc[i][0] += o[0]; acc[i][1] += o[1]; acc[i][2] += o[2]; acc[i][3] += o[3];
+    }
+
+    const int n = lane & 15, jj = n >> 3, co = n & 7;
+    const float bv = bias[co];
+    const int gz = z0 + zt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = y0 + yt0 + i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gx = x0 + 2 * m + jj;
+            if (gz < D && gy < H && gx < W) {
+                const float v = fmaxf(acc[i][e] + bv, 0.0f);
+                y[(((size_t)gz * H + gy) * W + gx) * 8 + co] = v;
+            }
+        }
+    }
+}
+
 int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
                       hipStream_t s) {
     using namespace c0;
@@ -172,8 +342,16 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias
         return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu floats exceeds 31-bit offsets",
                     (size_t)D * H * W * 8);
     const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
-    conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
-                                              static_cast<float*>(y), D, H, W);
+    static const bool four_waves = [] {  // MVS_CONV0_4W=1: the 256-thread variant (A/B runs)
+        const char* e = getenv("MVS_CONV0_4W");
+        return e && e[0] == '1';
+    }();
+    if (four_waves)
+        conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
+                                                  static_cast<float*>(y), D, H, W);
+    else
+        conv0_pair_mfma8_kernel<<<nb, 512, 0, s>>>(static_cast<const float*>(x), bp, bias,
+                                                   static_cast<float*>(y), D, H, W);
     return check_hip(hipGetLastError(), "conv0_mfma launch");
 }
 
