@@ -355,6 +355,219 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias
     return check_hip(hipGetLastError(), "conv0_mfma launch");
 }
 
+// =============================================================================================
+// Generic fp32-MFMA implicit-GEMM 3x3x3 convolution (stride 1 or 2), Cout a multiple of 16:
+// conv1..conv6 of CostRegNet (models/mvsnet.py:38-45; ConvBnReLU3D of models/module.py:26-33).
+//
+//   M : output voxels; one MFMA tile = 2(y) x 8(x) voxels (W, H are multiples of 8 / 2 at every
+//       level the ABI admits, so tiles never straddle a row end except on ragged shapes: masked)
+//   N : 16 output channels per N-tile, NT = COUT/16 tiles
+//   K : (tap, ci): chunks of 8 input channels (= one C8 plane), 27 taps padded to 28 so that a
+//       k-step of 16 is exactly 2 taps x 8 channels: 14 k-steps per chunk
+//   A[m][k] = in[S*oz+kz-1][S*oy+ky-1][S*ox+kx-1][ci]         B[k][n] = w[tap][ci][co]
+// Block = 4 waves = NT N-tiles x MG M-groups of MPW M-tiles each; the block tile is BZ x BY x BX
+// M-tiles.  Per chunk the input halo tile is staged in LDS (row pitch padded to a multiple of 8
+// voxels, voxel stride 32 B for stride 1 / 48 B for stride 2: conflict-free ds_read_b128), the
+// (chunk, N-tile) B panel sits in registers (56 VGPRs), staging of chunk c+1 overlaps the MFMAs
+// of chunk c exactly as in the conv0 kernel above.
+// =============================================================================================
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+struct ConvG {
+    static constexpr int NT = COUT / 16;
+    static constexpr int MG = 4 / NT;
+    static constexpr int MT = BZ * BY * BX;
+    static constexpr int MPW = MT / MG;
+    static constexpr int NCH = CIN / 8;
+    static constexpr int KS = 14;
+    static constexpr int VS = (S == 1) ? 8 : 12;
+    static constexpr int HZ = (BZ - 1) * S + 3, HY = (2 * BY - 1) * S + 3, HX = (8 * BX - 1) * S + 3;
+    static constexpr int HXP = (HX + 7) / 8 * 8;
+    static constexpr int TILE_FLOATS = HZ * HY * HXP * VS;
+    static constexpr int NPIECE = HZ * HY * HX * 2;
+    static constexpr int PPT = (NPIECE + 255) / 256;
+    static_assert(NT == 1 || NT == 2 || NT == 4, "COUT must be 16, 32 or 64");
+    static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
+    static_assert(PPT <= 32, "piece mask is 32 bits");
+    static constexpr int tap_off(int tap) {  // LDS float offset of tap (kz,ky,kx); tap 27 = padding
+        const int t = tap > 26 ? 26 : tap;
+        return (((t / 9) * HY + (t / 3) % 3) * HXP + t % 3) * VS;
+    }
+};
+
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void convg_mfma_kernel(
+    const float* __restrict__ x,     // [CIN/8][Di][Hi][Wi][8]
+    const float* __restrict__ bp,    // [NCH][NT][14][64][4]
+    const float* __restrict__ bias,  // [COUT]
+    float* __restrict__ y,           // [COUT/8][Do][Ho][Wo][8]
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+    using G = ConvG<CIN, COUT, S, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NT, mg = wave / G::NT;
+    const int nbx = (Wo + 8 * BX - 1) / (8 * BX), nby = (Ho + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ox0 = bx * 8 * BX, oy0 = by * 2 * BY, oz0 = bz * BZ;  // first output voxel of the block
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;  // halo origin (input coords)
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = (size_t)Do * Ho * Wo;
+
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = p < G::NPIECE && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8 + half * 4) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (p < G::NPIECE) ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS + half * 4 : -1;
+    }
+
+    // A fragment: lane (r = lane&15 -> voxel (ry, rx) of the M-tile, g = lane>>4): k-step ks covers
+    // taps 2ks (g>>1 == 0) and 2ks+1 (g>>1 == 1), channels 4(g&1)..+3 of the chunk
+    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = (((tz * S) * G::HY + (2 * ty + ry) * S) * G::HXP + (8 * tx + rx) * S) * G::VS + (g & 1) * 4;
+    }
+
+    f32x4 acc[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 breg[G::KS];
+    f32x4 stg[G::PPT];
+
+#define MVS_LOAD_B(C)                                                                               \
+    {                                                                                               \
+        const f32x4* bsrc =                                                                         \
+            reinterpret_cast<const f32x4*>(bp) + ((size_t)((C) * G::NT + nt) * G::KS) * 64 + lane;  \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];              \
+    }
+#define MVS_LOAD_A(C)                                                                               \
+    {                                                                                               \
+        const float* plane = x + (size_t)(C) * Vin * 8;                                             \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                              \
+    }
+#define MVS_STORE_A()                                                                               \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            if (loff[i] >= 0)                                                                       \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                         \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};                    \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int koff = gh ? G::tap_off(2 * ks + 1) : G::tap_off(2 * ks);
+            f32x4 a[G::MPW];
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) a[i] = *reinterpret_cast<const f32x4*>(tile + abase[i] + koff);
+            const f32x4 bq = breg[ks];
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
+        }
+        if (c + 1 < G::NCH) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    // epilogue: D layout col n = lane&15 -> co = 16 nt + n; row m = 4*(lane>>4) + e -> voxel of tile
+    const int n = lane & 15, co = 16 * nt + n;
+    const float bv = bias[co];
+    float* yplane = y + (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = oz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
+            if (gz < Do && gy < Ho && gx < Wo)
+                yplane[(((size_t)gz * Ho + gy) * Wo + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+        }
+    }
+}
+
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+static int run_convg(const void* x, void* y, const float* bp, const float* bias, int Di, int Hi, int Wi,
+                     hipStream_t s) {
+    const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
+    convg_mfma_kernel<CIN, COUT, S, BZ, BY, BX><<<nb, 256, 0, s>>>(
+        static_cast<const float*>(x), bp, bias, static_cast<float*>(y), Di, Hi, Wi, Do, Ho, Wo);
+    return check_hip(hipGetLastError(), "convg_mfma launch");
+}
+
+// layers 1..6 (conv1..conv6)
+int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
+                      int Hi, int Wi, hipStream_t s) {
+    switch (layer) {
+        case 1: return run_convg<8, 16, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 2: return run_convg<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convg<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 4: return run_convg<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 5: return run_convg<32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 6: return run_convg<64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: layer %d not covered", layer);
+    }
+}
+
+// Host-side packing for convg: wfold [27][cin][cout] -> bp [cin/8][cout/16][14][64][4]
+void pack_convg_weights(const float* wfold, int cin, int cout, float* bp) {
+    const int nch = cin / 8, nt = cout / 16;
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < nt; ++t)
+            for (int ks = 0; ks < 14; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const int g = lane >> 4, n = lane & 15;
+                        const int tap = 2 * ks + (g >> 1);
+                        const int ci = 8 * c + 4 * (g & 1) + j4, co = 16 * t + n;
+                        const float v = tap < 27 ? wfold[((size_t)tap * cin + ci) * cout + co] : 0.0f;
+                        bp[((((size_t)c * nt + t) * 14 + ks) * 64 + lane) * 4 + j4] = v;
+                    }
+}
+
+size_t convg_panel_floats(int cin, int cout) { return (size_t)(cin / 8) * (cout / 16) * 14 * 64 * 4; }
+
 // Host-side packing of the Toeplitz-expanded conv0 weights in per-lane fragment order.
 //   wfold [27][32][8]  BN-folded tap-major weights  ->  bp [4][18][64][4]
 void pack_conv0_pair_weights(const float* wfold, float* bp) {

@@ -91,6 +91,25 @@ def test_pack_weights_folds_bn_and_relayouts():
             want = w0[kz, ky, kx, ci, co] if 0 <= kx <= 2 else 0.0
             assert panel[c, ks, lane, j4] == want
     off += 4 * 18 * 64 * 4
+    # generic MFMA panels of layers 1..6: [cin/8][cout/16][14 k-steps][64 lanes][4]
+    woffs, o = [], 0
+    for l in range(11):
+        ci, co = layer_ch[l]
+        woffs.append(o)
+        o = (o + 27 * ci * co + 63) // 64 * 64
+        o = (o + co + 63) // 64 * 64
+    for l in range(1, 7):
+        ci, co = layer_ch[l]
+        nch, nt = ci // 8, co // 16
+        panel = blob[off:off + nch * nt * 14 * 64 * 4].reshape(nch, nt, 14, 64, 4)
+        wl = blob[woffs[l]:woffs[l] + 27 * ci * co].reshape(27, ci, co)
+        for c, t, ks, lane in [(0, 0, 0, 0), (nch - 1, nt - 1, 13, 63), (nch // 2, 0, 7, 21)]:
+            g, n = lane >> 4, lane & 15
+            tap = 2 * ks + (g >> 1)
+            for j4 in range(4):
+                want = wl[tap, 8 * c + 4 * (g & 1) + j4, 16 * t + n] if tap < 27 else 0.0
+                assert panel[c, t, ks, lane, j4] == want
+        off += nch * nt * 14 * 64 * 4
     assert off * 4 == _lib.query_weights_blob()
 
 
