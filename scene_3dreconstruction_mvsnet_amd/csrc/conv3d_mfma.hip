@@ -342,11 +342,11 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias
         return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu floats exceeds 31-bit offsets",
                     (size_t)D * H * W * 8);
     const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
-    static const bool four_waves = [] {  // MVS_CONV0_4W=1: the 256-thread variant (A/B runs)
-        const char* e = getenv("MVS_CONV0_4W");
+    static const bool eight_waves = [] {  // MVS_CONV0_8W=1: the 512-thread split-K variant (A/B runs;
+        const char* e = getenv("MVS_CONV0_8W");  // measured slower: 0.69 vs 0.64 ms at cfg2)
         return e && e[0] == '1';
     }();
-    if (four_waves)
+    if (!eight_waves)
         conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
                                                   static_cast<float*>(y), D, H, W);
     else
