@@ -324,6 +324,9 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.b_off[0], Di, Hi, Wi, s);
     if (layer >= 1 && layer <= 6 && !force_direct())
         return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
+    if (layer >= 7 && layer <= 9 && !force_direct())
+        return launch_deconvg_mfma(layer, x, skip, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di,
+                                   Hi, Wi, s);
     return launch_conv_layer_direct(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer],
                                     Di, Hi, Wi, dtype, s);
 }

@@ -568,6 +568,238 @@ void pack_convg_weights(const float* wfold, int cin, int cout, float* bp) {
 
 size_t convg_panel_floats(int cin, int cout) { return (size_t)(cin / 8) * (cout / 16) * 14 * 64 * 4; }
 
+// =============================================================================================
+// fp32-MFMA transposed convolution: ConvTranspose3d k3 s2 p1 op1 (+folded BN) + ReLU + skip add,
+// conv7 / conv9 / conv11 of CostRegNet (models/mvsnet.py:47-60, 69-71).
+//
+// Gather form per axis:  o = 2i - 1 + k  =>  even o = 2i: (k=1, input i);  odd o = 2i+1:
+// (k=2, input i) and (k=0, input i+1).  The GEMM runs over the INPUT grid:
+//   M : input voxels i (MFMA tile = 2(y) x 8(x)); each produces the 2x2x2 outputs 2i+p
+//   classes (pz, py): 4 accumulator sets; their (z,y) taps: 1x1, 1x2, 2x1, 2x2 input offsets
+//   N : (px, co) -- the x parity is folded into N, so both x taps (dx = 0, 1) are always
+//       present: B[(dz,dy,dx),ci][(px,co)] = w[kz][ky][kx][ci][co] with kx = 1 / none for px=0
+//       (dx = 0 / 1) and kx = 2 / 0 for px=1   -> 3/4 of the MFMA work is useful and Cout = 8
+//       (conv11) fills the 16 MFMA columns
+//   K : per chunk of 8 input channels 18 (tap, dx) pairs = 9 k-steps of 16 over the 4 classes
+// The input halo tile (BZ+1 x 2BY+1 x 8BX+1 voxels) is staged once per chunk and serves all
+// 8 output parities.  Epilogue: ReLU(acc + bias) + skip  (skip + relu(bn(deconv)), mvsnet.py:69).
+// =============================================================================================
+template <int CIN, int COUT, int BZ, int BY, int BX>
+struct DeconvG {
+    static constexpr int NTT = 2 * COUT / 16;  // N-tiles over (px, co)
+    static constexpr int MG = 4 / NTT;
+    static constexpr int MT = BZ * BY * BX;
+    static constexpr int MPW = MT / MG;
+    static constexpr int NCH = CIN / 8;
+    static constexpr int KS = 9;
+    static constexpr int VS = 8;
+    static constexpr int HZ = BZ + 1, HY = 2 * BY + 1, HX = 8 * BX + 1;
+    static constexpr int HXP = (HX + 7) / 8 * 8;
+    static constexpr int TILE_FLOATS = HZ * HY * HXP * VS;
+    static constexpr int NPIECE = HZ * HY * HX * 2;
+    static constexpr int PPT = (NPIECE + 255) / 256;
+    static_assert(NTT == 1 || NTT == 2 || NTT == 4, "COUT must be 8, 16 or 32");
+    static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
+};
+
+// k-step -> (class, kz, dz, ky, dy); shared by the kernel and the host packer
+struct DeconvStep { int cls, kz, dz, ky, dy; };
+__host__ __device__ constexpr DeconvStep deconv_step(int ks) {
+    // z/y tap lists: parity 0 -> {(k=1,d=0)}; parity 1 -> {(k=2,d=0), (k=0,d=1)}
+    // ks 0: cls0 | 1,2: cls1 (py=1) | 3,4: cls2 (pz=1) | 5..8: cls3 (pz=1, py=1)
+    return ks == 0 ? DeconvStep{0, 1, 0, 1, 0}
+         : ks == 1 ? DeconvStep{1, 1, 0, 2, 0}
+         : ks == 2 ? DeconvStep{1, 1, 0, 0, 1}
+         : ks == 3 ? DeconvStep{2, 2, 0, 1, 0}
+         : ks == 4 ? DeconvStep{2, 0, 1, 1, 0}
+         : ks == 5 ? DeconvStep{3, 2, 0, 2, 0}
+         : ks == 6 ? DeconvStep{3, 2, 0, 0, 1}
+         : ks == 7 ? DeconvStep{3, 0, 1, 2, 0}
+                   : DeconvStep{3, 0, 1, 0, 1};
+}
+
+template <int CIN, int COUT, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void deconvg_mfma_kernel(
+    const float* __restrict__ x,     // [CIN/8][Di][Hi][Wi][8]
+    const float* __restrict__ bp,    // [NCH][NTT][9][64][4]
+    const float* __restrict__ bias,  // [COUT]
+    const float* __restrict__ skip,  // [COUT/8][2Di][2Hi][2Wi][8]
+    float* __restrict__ y,           // [COUT/8][2Di][2Hi][2Wi][8]
+    int Di, int Hi, int Wi) {
+    using G = DeconvG<CIN, COUT, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NTT, mg = wave / G::NTT;
+    const int nbx = (Wi + 8 * BX - 1) / (8 * BX), nby = (Hi + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ix0 = bx * 8 * BX, iy0 = by * 2 * BY, iz0 = bz * BZ;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = Vin * 8;
+
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = p < G::NPIECE && gz < Di && gy < Hi && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8 + half * 4) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (p < G::NPIECE) ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS + half * 4 : -1;
+    }
+
+    // lane (r -> input voxel (ry, rx) of the M-tile, g): dx = g>>1, channels 4(g&1)..+3
+    const int r = lane & 15, g = lane >> 4;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = ((tz * G::HY + 2 * ty + ry) * G::HXP + 8 * tx + rx + (g >> 1)) * G::VS + (g & 1) * 4;
+    }
+
+    f32x4 acc[4][G::MPW];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 breg[G::KS];
+    f32x4 stg[G::PPT];
+
+#define MVS_LOAD_B(C)                                                                               \
+    {                                                                                               \
+        const f32x4* bsrc =                                                                         \
+            reinterpret_cast<const f32x4*>(bp) + ((size_t)((C) * G::NTT + nt) * G::KS) * 64 + lane; \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];              \
+    }
+#define MVS_LOAD_A(C)                                                                               \
+    {                                                                                               \
+        const float* plane = x + (size_t)(C) * Vin * 8;                                             \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                              \
+    }
+#define MVS_STORE_A()                                                                               \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            if (loff[i] >= 0)                                                                       \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                         \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};                    \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const DeconvStep st = deconv_step(ks);
+            const int koff = (st.dz * G::HY + st.dy) * G::HXP * G::VS;
+            f32x4 a[G::MPW];
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) a[i] = *reinterpret_cast<const f32x4*>(tile + abase[i] + koff);
+            const f32x4 bq = breg[ks];
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[st.cls][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[st.cls][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[st.cls][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[st.cls][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[st.cls][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[st.cls][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) acc[st.cls][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[st.cls][i], 0, 0, 0);
+        }
+        if (c + 1 < G::NCH) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    // epilogue: col n -> (px, co); row m -> input voxel of the tile; class -> (pz, py)
+    const int nn = 16 * nt + (lane & 15);
+    const int px = nn / COUT, co = nn % COUT;
+    const float bv = bias[co];
+    const size_t plane_off = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = iz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = iy0 + 2 * ty + (m >> 3), gx = ix0 + 8 * tx + (m & 7);
+            if (gz < Di && gy < Hi && gx < Wi) {
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
+                    const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
+                    y[o] = fmaxf(acc[cls][i][e] + bv, 0.0f) + skip[o];
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int BZ, int BY, int BX>
+static int run_deconvg(const void* x, const void* skip, void* y, const float* bp, const float* bias,
+                       int Di, int Hi, int Wi, hipStream_t s) {
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wi + 8 * BX - 1) / (8 * BX)) * ((Hi + 2 * BY - 1) / (2 * BY)) * ((Di + BZ - 1) / BZ);
+    deconvg_mfma_kernel<CIN, COUT, BZ, BY, BX><<<nb, 256, 0, s>>>(
+        static_cast<const float*>(x), bp, bias, static_cast<const float*>(skip),
+        static_cast<float*>(y), Di, Hi, Wi);
+    return check_hip(hipGetLastError(), "deconvg_mfma launch");
+}
+
+// layers 7..9 (conv7, conv9, conv11)
+int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
+                        const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
+    switch (layer) {
+        case 7: return run_deconvg<64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 8: return run_deconvg<32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 9: return run_deconvg<16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: layer %d not covered", layer);
+    }
+}
+
+// Host-side packing for deconvg: wfold [27][cin][cout] -> bp [cin/8][2*cout/16][9][64][4]
+void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp) {
+    const int nch = cin / 8, ntt = 2 * cout / 16;
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < ntt; ++t)
+            for (int ks = 0; ks < 9; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const DeconvStep st = deconv_step(ks);
+                        const int g = lane >> 4, n = lane & 15, dx = g >> 1;
+                        const int ci = 8 * c + 4 * (g & 1) + j4;
+                        const int nn = 16 * t + n, px = nn / cout, co = nn % cout;
+                        const int kx = px == 0 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 2 : 0);
+                        const float v = kx < 0 ? 0.0f
+                                               : wfold[((size_t)(st.kz * 9 + st.ky * 3 + kx) * cin + ci) * cout + co];
+                        bp[((((size_t)c * ntt + t) * 9 + ks) * 64 + lane) * 4 + j4] = v;
+                    }
+}
+
 // Host-side packing of the Toeplitz-expanded conv0 weights in per-lane fragment order.
 //   wfold [27][32][8]  BN-folded tap-major weights  ->  bp [4][18][64][4]
 void pack_conv0_pair_weights(const float* wfold, float* bp) {

@@ -40,7 +40,7 @@ struct BlobLayout {
     size_t w_off[MVS_NUM_LAYERS];  // in floats
     size_t b_off[MVS_NUM_LAYERS];  // in floats
     size_t c0p_off;                // conv0 Toeplitz "pair" panel [4][18][64][4] (conv3d_mfma.hip)
-    size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 (0 = none)
+    size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 and deconv panels of 7..9
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -59,6 +59,10 @@ inline BlobLayout blob_layout() {
     for (int l = 1; l <= 6; ++l) {
         L.gp_off[l] = off;
         off += (size_t)(kLayers[l].cin / 8) * (kLayers[l].cout / 16) * 14 * 64 * 4;
+    }
+    for (int l = 7; l <= 9; ++l) {
+        L.gp_off[l] = off;
+        off += (size_t)(kLayers[l].cin / 8) * (2 * kLayers[l].cout / 16) * 9 * 64 * 4;
     }
     L.total_floats = off;
     return L;
@@ -119,6 +123,9 @@ void pack_conv0_pair_weights(const float* wfold, float* bp);
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
                       int Hi, int Wi, hipStream_t s);
 void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);
+int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
+                        const float* bias, int Di, int Hi, int Wi, hipStream_t s);
+void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s);
 int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,

@@ -110,6 +110,9 @@ def test_pack_weights_folds_bn_and_relayouts():
                 want = wl[tap, 8 * c + 4 * (g & 1) + j4, 16 * t + n] if tap < 27 else 0.0
                 assert panel[c, t, ks, lane, j4] == want
         off += nch * nt * 14 * 64 * 4
+    for l in range(7, 10):  # deconv panels [cin/8][2*cout/16][9][64][4]
+        ci, co = layer_ch[l]
+        off += (ci // 8) * (2 * co // 16) * 9 * 64 * 4
     assert off * 4 == _lib.query_weights_blob()
 
 
