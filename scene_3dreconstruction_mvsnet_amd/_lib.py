@@ -14,7 +14,7 @@ import threading
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_hip.so")
+LIB_PATH = os.environ.get("MVS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 MVS_F32, MVS_F16, MVS_BF16 = 0, 1, 2
 NUM_LAYERS = 11

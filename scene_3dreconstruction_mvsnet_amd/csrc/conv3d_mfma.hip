@@ -28,6 +28,13 @@ namespace mvs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (make ABLATE=n -> libmvs_hip_ablate<n>.so, wrong results by design):
+//   1 = conv0 without epilogue stores, 2 = without chunk re-staging, 3 = also without the
+//   staging loads.  Product builds leave MVS_ABLATE at 0.
+#ifndef MVS_ABLATE
+#define MVS_ABLATE 0
+#endif
+
 namespace c0 {
 constexpr int TZ = 2, TY = 8, TX = 32;              // output tile
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;  // halo tile
@@ -117,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
     const float* abase = tile + lane_off;
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
+#if MVS_ABLATE != 3
         if (c < 3) MVS_LOAD_A(c + 1)
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int tap0 = 2 * ks;  // taps (kz, ky, kx') with kx' = tap % 4
@@ -137,12 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
         }
+#if MVS_ABLATE != 2 && MVS_ABLATE != 3
         if (c < 3) {
             MVS_LOAD_B(c + 1)
             __syncthreads();  // every wave is done reading chunk c's tile
             MVS_STORE_A()
             __syncthreads();
         }
+#endif
     }
 #undef MVS_LOAD_B
 #undef MVS_LOAD_A
@@ -159,7 +170,11 @@ __global__ __launch_bounds__(256, 2) void conv0_pair_mfma_kernel(
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * (lane >> 4) + e;
             const int gx = x0 + 2 * m + jj;
+#if MVS_ABLATE == 1
+            if (gz < D && gy < H && gx < W && acc[i][e] == 12345.678f) {
+#else
             if (gz < D && gy < H && gx < W) {
+#endif
                 const float v = fmaxf(acc[i][e] + bv, 0.0f);  // ReLU(BN(conv)) with BN folded
                 y[(((size_t)gz * H + gy) * W + gx) * 8 + co] = v;
             }
