@@ -321,7 +321,7 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
     if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "conv3d: dtype %d not implemented", dtype);
     const BlobLayout L = blob_layout();
     if (layer == 0 && !force_direct())
-        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.b_off[0], Di, Hi, Wi, s);
+        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, s);
     if (layer >= 1 && layer <= 6 && !force_direct())
         return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
     if (layer >= 7 && layer <= 9 && !force_direct())

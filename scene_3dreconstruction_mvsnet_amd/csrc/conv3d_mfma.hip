@@ -350,8 +350,159 @@ __global__ __launch_bounds__(512, 4) void conv0_pair_mfma8_kernel(
     }
 }
 
-int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
-                      hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// conv0 on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products per instruction (512 FLOP
+// in 8 cycles = the same 64 FLOP/clk/SIMD as the 16x16x4 form), so N = 4 output channels per
+// tile and Cout = 8 is two exact N-tiles: no padded or Toeplitz-wasted columns (the pair kernel
+// above spends 4/3 of the useful MFMA cycles).
+//   lane l = 4*blk + i supplies A = in[voxel l of the 64-voxel M-group][k] and B = w[k][4*nt + i];
+//   D: lane 4*blk + j, register i' = out[voxel 4*blk + i'][4*nt + j]   (probed on gfx950:
+//   tools/probes/mfma4x4_probe.hip)
+// Same 2 x 8 x 32 output tile, halo staging (48-byte voxel stride keeps the 64 x 16 B A reads
+// conflict-free) and chunk pipeline as conv0_pair_mfma_kernel; a wave owns two M-groups (2 rows x
+// 32 x each).  The chunk's weights (27 taps x 8 ci x 8 co = 6.9 KB, [tap][half][nt][j][4 k])
+// live in LDS next to the tile: every (tap, half) step is 2 A reads + 2 broadcast B reads
+// (ds_read_b128) feeding 16 MFMAs.
+// ---------------------------------------------------------------------------------------------
+namespace c0 {
+constexpr int BQ_FLOATS = 27 * 2 * 2 * 4 * 4;  // per chunk
+}
+
+__global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
+    const float* __restrict__ x,     // [4][D][H][W][8]
+    const float* __restrict__ bq,    // [4 chunks][27 taps][2 halves][2 nt][4 j][4 k]
+    const float* __restrict__ bias,  // [8]
+    float* __restrict__ y,           // [D][H][W][8]
+    int D, int H, int W) {
+    using namespace c0;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + BQ_FLOATS];
+    float* wlds = tile + TILE_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const size_t V = (size_t)D * H * W;
+
+    int goff[PIECES_PER_THREAD];
+    int loff[PIECES_PER_THREAD];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_THREAD; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, t = v / HX;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8 + half * 4) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (p < NPIECE) ? v * VS + half * 4 : -1;
+    }
+
+    // lane -> voxel (row, xl) of an M-group; wave -> z slice and 4 rows (two M-groups of 2 rows)
+    const int row = lane >> 5, xl = lane & 31;
+    const int zt = wave >> 1, yt0 = 4 * (wave & 1);
+    const float* abase0 = tile + ((zt * HY + yt0 + row) * HX + xl) * VS;
+    const float* abase1 = abase0 + 2 * HX * VS;
+    const float* wbase = wlds + (lane & 3) * 4;
+
+    f32x4 acc[2][2];  // [M-group][nt]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 stg[PIECES_PER_THREAD];
+    f32x4 wst[2];
+    constexpr int WPIECES = BQ_FLOATS / 4;  // 432 16-byte pieces of weights per chunk
+#define MVS_LOAD_A(C)                                                                         \
+    {                                                                                         \
+        const float* plane = x + (size_t)(C) * V * 8;                                         \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                        \
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(bq) + (size_t)(C) * WPIECES;       \
+        wst[0] = wsrc[tid];                                                                   \
+        wst[1] = wsrc[min(tid + 256, WPIECES - 1)];                                           \
+    }
+#define MVS_STORE_A()                                                                         \
+    {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
+            if (loff[i] >= 0)                                                                 \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                   \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};              \
+        reinterpret_cast<f32x4*>(wlds)[tid] = wst[0];                                         \
+        if (tid + 256 < WPIECES) reinterpret_cast<f32x4*>(wlds)[tid + 256] = wst[1];          \
+    }
+
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c < 3) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int koff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * VS;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(abase0 + koff + half * 4);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(abase1 + koff + half * 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(wbase + ((tap * 2 + half) * 2 + 0) * 16);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(wbase + ((tap * 2 + half) * 2 + 1) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], b0[k], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], b1[k], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[k], b0[k], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[k], b1[k], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        if (c < 3) {
+            __syncthreads();  // every wave is done reading chunk c's tile and weights
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    // epilogue: lane 4*blk + j, register i -> voxel 4*blk + i of the M-group, channel 4*nt + j
+    const int blk = lane >> 2, j = lane & 3;
+    const int gz = z0 + zt;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vox = 4 * blk + i;  // 0..63: (row, xl) = (vox >> 5, vox & 31)
+            const int gy = y0 + yt0 + 2 * m + (vox >> 5), gx = x0 + (vox & 31);
+            if (gz < D && gy < H && gx < W) {
+                float* o = y + (((size_t)gz * H + gy) * W + gx) * 8;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) o[4 * n + j] = fmaxf(acc[m][n][i] + bias[4 * n + j], 0.0f);
+            }
+        }
+}
+
+// wfold [27][32][8] -> bq [4 chunks][27][2 halves][2 nt][4 j][4 k]:  w[tap][8c + 4half + k][4nt + j]
+void pack_conv0_4x4_weights(const float* wfold, float* bq) {
+    for (int c = 0; c < 4; ++c)
+        for (int tap = 0; tap < 27; ++tap)
+            for (int half = 0; half < 2; ++half)
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int j = 0; j < 4; ++j)
+                        for (int k = 0; k < 4; ++k)
+                            bq[(((((size_t)c * 27 + tap) * 2 + half) * 2 + nt) * 4 + j) * 4 + k] =
+                                wfold[((size_t)tap * 32 + 8 * c + 4 * half + k) * 8 + 4 * nt + j];
+}
+
+int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, const float* bias,
+                      int D, int H, int W, hipStream_t s) {
     using namespace c0;
     if ((size_t)D * H * W * 8 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu floats exceeds 31-bit offsets",
@@ -361,7 +512,14 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias
         const char* e = getenv("MVS_CONV0_8W");  // measured slower: 0.69 vs 0.64 ms at cfg2)
         return e && e[0] == '1';
     }();
-    if (!eight_waves)
+    static const bool pair_kernel = [] {  // MVS_CONV0_PAIR=1: the 16x16x4 Toeplitz-pair kernel
+        const char* e = getenv("MVS_CONV0_PAIR");
+        return e && e[0] == '1';
+    }();
+    if (!pair_kernel && !eight_waves)
+        conv0_4x4_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bq, bias,
+                                                 static_cast<float*>(y), D, H, W);
+    else if (!eight_waves)
         conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
                                                   static_cast<float*>(y), D, H, W);
     else

@@ -40,6 +40,7 @@ struct BlobLayout {
     size_t w_off[MVS_NUM_LAYERS];  // in floats
     size_t b_off[MVS_NUM_LAYERS];  // in floats
     size_t c0p_off;                // conv0 Toeplitz "pair" panel [4][18][64][4] (conv3d_mfma.hip)
+    size_t c0q_off;                // conv0 4x4x1 panel [4][27][2][2][4][4] (conv3d_mfma.hip)
     size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 and deconv panels of 7..9
     size_t total_floats;
 };
@@ -56,6 +57,8 @@ inline BlobLayout blob_layout() {
     }
     L.c0p_off = off;
     off += (size_t)4 * 18 * 64 * 4;
+    L.c0q_off = off;
+    off += (size_t)4 * 27 * 2 * 2 * 4 * 4;
     for (int l = 1; l <= 6; ++l) {
         L.gp_off[l] = off;
         off += (size_t)(kLayers[l].cin / 8) * (kLayers[l].cout / 16) * 14 * 64 * 4;
@@ -117,9 +120,10 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
                       int Di, int Hi, int Wi, int dtype, hipStream_t s);
 int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y, const float* wgt,
                              const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
-int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
-                      hipStream_t s);
+int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, const float* bias,
+                      int D, int H, int W, hipStream_t s);
 void pack_conv0_pair_weights(const float* wfold, float* bp);
+void pack_conv0_4x4_weights(const float* wfold, float* bq);
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
                       int Hi, int Wi, hipStream_t s);
 void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);

@@ -91,6 +91,12 @@ def test_pack_weights_folds_bn_and_relayouts():
             want = w0[kz, ky, kx, ci, co] if 0 <= kx <= 2 else 0.0
             assert panel[c, ks, lane, j4] == want
     off += 4 * 18 * 64 * 4
+    # conv0 4x4x1 panel [4 chunks][27 taps][2 halves][2 nt][4 j][4 k]
+    q = blob[off:off + 4 * 27 * 2 * 2 * 4 * 4].reshape(4, 27, 2, 2, 4, 4)
+    w0t = blob[:27 * 32 * 8].reshape(27, 32, 8)
+    for c, tap, half, nt, j, k in [(0, 0, 0, 0, 0, 0), (3, 26, 1, 1, 3, 3), (1, 13, 0, 1, 2, 1)]:
+        assert q[c, tap, half, nt, j, k] == w0t[tap, 8 * c + 4 * half + k, 4 * nt + j]
+    off += 4 * 27 * 2 * 2 * 4 * 4
     # generic MFMA panels of layers 1..6: [cin/8][cout/16][14 k-steps][64 lanes][4]
     woffs, o = [], 0
     for l in range(11):
