@@ -107,23 +107,46 @@ def main():
     n_ev = len(stage_names) + 1
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(K)]
 
+    # Pre-allocated per-stream buffers and pre-bound C calls keep the host ahead of the GPU in the
+    # staged mode (no torch allocations or shape logic inside the timed loop).
+    lib = _lib.load()
+    V0 = D * h * w
+
+    def lvl(c, l):
+        return torch.empty((c // 8, D >> l, h >> l, w >> l, 8), dtype=torch.float32, device=dev)
+
+    bufs = []
+    for si in range(S):
+        bufs.append(dict(rt=torch.empty((max(N - 1, 1), 12), dtype=torch.float32, device=dev),
+                         var=lvl(32, 0),
+                         act=[lvl(8, 0), lvl(16, 1), lvl(16, 1), lvl(32, 2), lvl(32, 2), lvl(64, 3),
+                              lvl(64, 3), lvl(32, 2), lvl(16, 1), lvl(8, 0)],
+                         cost=torch.empty((D, h, w), dtype=torch.float32, device=dev)))
+    skips = {7: 4, 8: 2, 9: 0}
+
     def step_staged(k, ev=None):
-        ws = wss[k % S]
+        si = k % S
+        ws, B = wss[si], bufs[si]
+        st = _lib._stream(dev)
         rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
         rec(0)
-        rt = _lib.relative_proj(proj)
+        _lib.check(lib.mvs_relative_proj(proj.data_ptr(), B["rt"].data_ptr(), N, st))
         rec(1)
-        x = _lib.warp_variance(feats, rt, dv, ws)
+        _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
+                                         B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D, h,
+                                         w, 0, st))
         rec(2)
-        acts = {}
+        x = B["var"]
         for li in range(11):
-            skip = {7: acts.get(4), 8: acts.get(2), 9: acts.get(0)}.get(li)
-            x = _lib.conv_layer(li, x, skip, blob)
-            acts[li] = x
+            yb = B["cost"] if li == 10 else B["act"][li]
+            sk = B["act"][skips[li]].data_ptr() if li in skips else 0
+            lvin = LAYERS[li][3]
+            _lib.check(lib.mvs_conv_layer(li, x.data_ptr(), sk, yb.data_ptr(), blob.data_ptr(),
+                                          D >> lvin, h >> lvin, w >> lvin, 0, st))
+            x = yb
             rec(3 + li)
-        lib = _lib.load()
         _lib.check(lib.mvs_softargmin_conf(x.data_ptr(), dv.data_ptr(), out[k, 0].data_ptr(),
-                                           out[k, 1].data_ptr(), D, h, w, _lib._stream(dev)))
+                                           out[k, 1].data_ptr(), D, h, w, st))
         rec(14)
 
     def step_fused(k, ev=None):
