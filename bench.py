@@ -221,6 +221,20 @@ def main():
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": c["bytes"]}
 
+    # HBM traffic of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction; profiles/r01_traffic.json)
+    if roofline is not None and args.config == "cfg2":
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+                prof = json.load(f)["kernels"]
+            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel", "warp_variance": "mvs::warp_variance_kernel"}
+            ent = prof.get(kname.get(roofline["kernel"], ""))
+            if ent:
+                roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
+                roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
+
     path_bytes = sum(c["bytes"] for c in costs.values())
     path_flops = sum(c["flops"] for c in costs.values())
     stagewise_floor_s = sum(max(c["bytes"] / (HBM_PEAK_GBPS * 1e9),
