@@ -237,6 +237,25 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     np.testing.assert_allclose(out[0][:, 1], want[:, 1], atol=1e-5)
 
 
+@pytest.mark.parametrize("env", [
+    {"MVS_WARP_LDS": "1"},       # LDS-staged warp+variance kernel
+    {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
+    {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
+    {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
+])
+def test_optin_kernel_variants(env):
+    """The non-default kernels stay parity-green (selection is read once per process, so each
+    variant runs tests/variant_check.py in a child process; sequential, one GPU user at a time)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, os.path.join(here, "variant_check.py")], env=child_env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------------------ error behaviour
 def test_bad_shapes_return_status_not_crash():
     feats = torch.zeros((3, 32, 12, 16), device=DEV)  # h=12 not a multiple of 8
