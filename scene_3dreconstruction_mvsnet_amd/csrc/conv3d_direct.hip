@@ -265,8 +265,103 @@ __global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict_
         if (oz0 + j < D) y[(size_t)(oz0 + j) * hw + (size_t)oy * W + ox] = acc[j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// prob through LDS: a block stages the 6 x 10 x 34 halo tile of the 8-channel input once and
+// produces a 4 x 8 x 32 tile of logits (4 z-adjacent outputs per thread).  The global-gather
+// version above is bound by the vector-L1 path (every voxel is fetched up to 27 times); here
+// each voxel is fetched ~2x (halo) and the 54 taps per thread come from LDS.  The two 16-byte
+// halves of a voxel are swapped for odd groups of 8 x positions so that the 32-byte voxel
+// stride stays conflict-free for ds_read_b128.
+// ---------------------------------------------------------------------------------------------
+namespace pl {
+constexpr int TZ = 4, TY = 8, TX = 32;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+constexpr int NPIECE = HZ * HY * HX * 2;
+constexpr int PPT = (NPIECE + 255) / 256;  // 16
+}  // namespace pl
+
+__global__ __launch_bounds__(256, 2) void prob_lds_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ wgt,  // [27][8]
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, int D, int H, int W) {
+    using namespace pl;
+    __shared__ __attribute__((aligned(16))) float tile[HZ * HY * HX * 8];
+    const int tid = threadIdx.x;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+
+    float4 stg[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, t = v / HX;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t off = ok ? (((size_t)gz * H + gy) * W + gx) * 8 + half * 4 : 0;
+        const float4 val = *reinterpret_cast<const float4*>(x + off);
+        stg[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX;
+        if (p < NPIECE) *reinterpret_cast<float4*>(tile + v * 8 + ((half ^ ((hx >> 3) & 1)) * 4)) = stg[i];
+    }
+    __syncthreads();
+
+    const int tx = tid & 31, ty = tid >> 5;  // thread -> (y, x) of the tile, 4 z outputs
+    float acc[TZ];
+    const float bv = bias[0];
+#pragma unroll
+    for (int j = 0; j < TZ; ++j) acc[j] = bv;
+#pragma unroll
+    for (int c = 0; c < HZ; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hx = tx + kw;
+                const float* vp = tile + ((c * HY + ty + kh) * HX + hx) * 8;
+                const int sw = ((hx >> 3) & 1) * 4;
+                const float4 a = *reinterpret_cast<const float4*>(vp + sw);        // channels 0..3
+                const float4 bq = *reinterpret_cast<const float4*>(vp + (4 - sw));  // channels 4..7
+#pragma unroll
+                for (int j = 0; j < TZ; ++j) {
+                    const int kd = c - j;
+                    if (kd < 0 || kd > 2) continue;
+                    const float* wv = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * 8;
+                    acc[j] = fmaf(a.x, wv[0], fmaf(a.y, wv[1], fmaf(a.z, wv[2], fmaf(a.w, wv[3], acc[j]))));
+                    acc[j] = fmaf(bq.x, wv[4], fmaf(bq.y, wv[5], fmaf(bq.z, wv[6], fmaf(bq.w, wv[7], acc[j]))));
+                }
+            }
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy < H && gx < W) {
+#pragma unroll
+        for (int j = 0; j < TZ; ++j)
+            if (z0 + j < D) y[((size_t)(z0 + j) * H + gy) * W + gx] = acc[j];
+    }
+}
+
 static int run_prob(const void* x, void* y, const float* wgt, const float* bias, int D, int H, int W,
                     hipStream_t s) {
+    static const bool use_gather = [] {  // MVS_PROB_GATHER=1: the global-gather kernel (A/B runs)
+        const char* e = getenv("MVS_PROB_GATHER");
+        return e && e[0] == '1';
+    }();
+    if (!use_gather) {
+        using namespace pl;
+        const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+        prob_lds_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), wgt, bias,
+                                           static_cast<float*>(y), D, H, W);
+        return check_hip(hipGetLastError(), "prob_lds launch");
+    }
     const size_t nthreads = (size_t)H * W * ((D + kProbZPT - 1) / kProbZPT);
     prob_conv_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(
         static_cast<const float*>(x), wgt, bias, static_cast<float*>(y), D, H, W);

@@ -7,7 +7,7 @@
 //                             confidence = sum4[idx] = p[idx-1]+p[idx]+p[idx+1]+p[idx+2]
 //
 // cost is [D][h][w] fp32: consecutive lanes = consecutive pixels, so every depth row is read
-// fully coalesced.  A block owns 64 pixels; its 4 waves split D into 4 slices, each doing an
+// fully coalesced.  A block owns 32 pixels; its 256 threads split D into 8 slices, each doing an
 // online softmax (running max / sum / weighted sums), merged through LDS.  HBM-bound:
 // algorithmic bytes = D*h*w*4 + 2*h*w*4.
 #include "mvs_internal.h"
@@ -19,11 +19,12 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
                                                               float* __restrict__ depth,
                                                               float* __restrict__ conf, int D,
                                                               int hw) {
-    __shared__ float s_m[4][64], s_s[4][64], s_d[4][64], s_i[4][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    constexpr int PIX = 32, NS = 8;  // pixels per block, depth slices (256 threads)
+    __shared__ float s_m[NS][PIX], s_s[NS][PIX], s_d[NS][PIX], s_i[NS][PIX];
+    const int lane = threadIdx.x & (PIX - 1), slice = threadIdx.x / PIX;
+    const int p = blockIdx.x * PIX + lane;
     const bool active = p < hw;
-    const int per = (D + 3) / 4;
+    const int per = (D + NS - 1) / NS;
     const int d0 = slice * per, d1 = min(d0 + per, D);
     float m = -INFINITY, s = 0.0f, sd = 0.0f, si = 0.0f;
     if (active) {
@@ -43,10 +44,12 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
     s_m[slice][lane] = m; s_s[slice][lane] = s; s_d[slice][lane] = sd; s_i[slice][lane] = si;
     __syncthreads();
     if (slice != 0 || !active) return;
-    float M = fmaxf(fmaxf(s_m[0][lane], s_m[1][lane]), fmaxf(s_m[2][lane], s_m[3][lane]));
+    float M = s_m[0][lane];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) M = fmaxf(M, s_m[k][lane]);
     float S = 0.0f, SD = 0.0f, SI = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const float r = (s_m[k][lane] == -INFINITY) ? 0.0f : expf(s_m[k][lane] - M);
         S = fmaf(s_s[k][lane], r, S);
         SD = fmaf(s_d[k][lane], r, SD);
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s) {
     const int hw = h * w;
-    softargmin_conf_kernel<<<(hw + 63) / 64, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+    softargmin_conf_kernel<<<(hw + 31) / 32, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
     return check_hip(hipGetLastError(), "softargmin launch");
 }
 
