@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const float* __restric
     for (int j = 0; j < TZ; ++j) acc[j] = bv;
 #pragma unroll
     for (int c = 0; c < HZ; ++c)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh)  // not unrolled: keeps the live LDS reads (and VGPRs) bounded
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int hx = tx + kw;
