@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"],
+                    help="storage dtype of the private volumes (arithmetic is always fp32); default: "
+                         "f32 for cfg1/cfg2, bf16 for cfg3, f16 for cfg5 as BASELINE.json names them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams to round-robin independent maps over (each has its own workspace)")
@@ -87,6 +90,9 @@ def main():
     cfg = synthetic.CONFIGS[args.config]
     N, D, h, w = cfg["nviews"], cfg["D"], cfg["H"] // 4, cfg["W"] // 4
     K, Wm = args.steps, args.warmup
+    storage = args.dtype or {"cfg3": "bf16", "cfg5": "f16"}.get(args.config, "f32")
+    dt = _lib.dtype_code(storage)
+    es = 4 if storage == "f32" else 2
     _lib.load()
 
     # ---- synthetic problem (per-rank seed: every rank owns different ref views) -------------
@@ -99,7 +105,7 @@ def main():
     dv = torch.from_numpy(dv_np).to(dev)
     blob = _lib.pack_weights(sd).to(dev)
     S = max(1, args.streams)
-    wss = [_lib.alloc_workspace(N, 32, D, h, w, dev) for _ in range(S)]
+    wss = [_lib.alloc_workspace(N, 32, D, h, w, dev, dt) for _ in range(S)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
@@ -113,7 +119,7 @@ def main():
     V0 = D * h * w
 
     def lvl(c, l):
-        return torch.empty((c // 8, D >> l, h >> l, w >> l, 8), dtype=torch.float32, device=dev)
+        return torch.empty((c // 8, D >> l, h >> l, w >> l, 8), dtype=_lib.TORCH_DTYPES[dt], device=dev)
 
     bufs = []
     for si in range(S):
@@ -134,7 +140,7 @@ def main():
         rec(1)
         _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
                                          B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D, h,
-                                         w, 0, st))
+                                         w, dt, st))
         rec(2)
         x = B["var"]
         for li in range(11):
@@ -142,7 +148,7 @@ def main():
             sk = B["act"][skips[li]].data_ptr() if li in skips else 0
             lvin = LAYERS[li][3]
             _lib.check(lib.mvs_conv_layer(li, x.data_ptr(), sk, yb.data_ptr(), blob.data_ptr(),
-                                          D >> lvin, h >> lvin, w >> lvin, 0, st))
+                                          D >> lvin, h >> lvin, w >> lvin, dt, st))
             x = yb
             rec(3 + li)
         _lib.check(lib.mvs_softargmin_conf(x.data_ptr(), dv.data_ptr(), out[k, 0].data_ptr(),
@@ -151,7 +157,7 @@ def main():
 
     def step_fused(k, ev=None):
         ws = wss[k % S]
-        _lib.depth_infer(feats, proj, dv, blob, ws, out[k, 0], out[k, 1])
+        _lib.depth_infer(feats, proj, dv, blob, ws, out[k, 0], out[k, 1], dtype=dt)
 
     step_one = step_fused if args.fused_call else step_staged
 
@@ -190,7 +196,7 @@ def main():
     ms_per_step = elapsed / K * 1e3
 
     # ---- per-stage durations from the events of the timed steps -----------------------------
-    costs = stage_costs(N, D, h, w)
+    costs = stage_costs(N, D, h, w, es)
     stages = {}
     if not args.fused_call:
         for si, name in enumerate(stage_names):
@@ -246,7 +252,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         tc = time.perf_counter()
-        depth_o, conf_o = orc.depth_infer(feats_np, proj_np, dv_np, sd)
+        depth_o, conf_o = orc.depth_infer(feats_np, proj_np, dv_np, sd, storage=storage)
         tc = time.perf_counter() - tc
         cpu_baseline = {"value": round(1.0 / tc, 5), "unit": "depth maps/s", "cores": orc.num_threads(),
                         "kind": "port",
@@ -261,9 +267,11 @@ def main():
                       if args.config == "cfg2" else f"depth maps/sec ({args.config})",
             "value": round(maps_per_s, 3), "unit": "depth maps/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if storage == "f32" else f"f32 arithmetic, {storage} storage",
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N} views, {cfg['H']}x{cfg['W']} image -> "
-                                   f"{h}x{w} features, D={D}, C=32, fp32; path-only (features "
+                                   f"{h}x{w} features, D={D}, C=32, {storage} volumes; path-only (features "
                                    "resident in HBM -> depth+confidence)",
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",

@@ -132,21 +132,43 @@ def _bn(sd, prefix):
             sd[prefix + ".running_var"])
 
 
-def costreg_forward(var, sd):
+def round_storage(a, storage="f32"):
+    """Round an fp32 array to the storage dtype of the HIP path's volumes and back to fp32.
+
+    The reference is fp32 throughout; the 16-bit storage variants (BASELINE.json configs 2/4) keep
+    fp32 arithmetic and narrow only what is written between stages.  This gives the
+    "quantisation-point-matched" oracle of SURVEY.md §7: same rounding points, same RNE rounding.
+    """
+    if storage in ("f32", None):
+        return a
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if storage == "f16":
+        return a.astype(np.float16).astype(np.float32)
+    if storage == "bf16":
+        u = a.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+        return np.where(np.isnan(a), a, out)
+    raise ValueError(storage)
+
+
+def costreg_forward(var, sd, storage="f32"):
     """CostRegNet.forward (models/mvsnet.py:64-73): var [32,D,h,w] -> cost [D,h,w].
 
     `sd` maps reference parameter names *relative to cost_regularization* to numpy arrays.
+    `storage` != "f32" rounds every stored activation (see round_storage); logits stay fp32.
     """
-    c0 = conv3d(var, sd["conv0.conv.weight"], bn=_bn(sd, "conv0.bn"))
-    c1 = conv3d(c0, sd["conv1.conv.weight"], bn=_bn(sd, "conv1.bn"), stride=2)
-    c2 = conv3d(c1, sd["conv2.conv.weight"], bn=_bn(sd, "conv2.bn"))
-    c3 = conv3d(c2, sd["conv3.conv.weight"], bn=_bn(sd, "conv3.bn"), stride=2)
-    c4 = conv3d(c3, sd["conv4.conv.weight"], bn=_bn(sd, "conv4.bn"))
-    c5 = conv3d(c4, sd["conv5.conv.weight"], bn=_bn(sd, "conv5.bn"), stride=2)
-    c6 = conv3d(c5, sd["conv6.conv.weight"], bn=_bn(sd, "conv6.bn"))
-    x = c4 + deconv3d(c6, sd["conv7.0.weight"], bn=_bn(sd, "conv7.1"))
-    x = c2 + deconv3d(x, sd["conv9.0.weight"], bn=_bn(sd, "conv9.1"))
-    x = c0 + deconv3d(x, sd["conv11.0.weight"], bn=_bn(sd, "conv11.1"))
+    q = lambda t: round_storage(t, storage)  # noqa: E731
+    c0 = q(conv3d(var, sd["conv0.conv.weight"], bn=_bn(sd, "conv0.bn")))
+    c1 = q(conv3d(c0, sd["conv1.conv.weight"], bn=_bn(sd, "conv1.bn"), stride=2))
+    c2 = q(conv3d(c1, sd["conv2.conv.weight"], bn=_bn(sd, "conv2.bn")))
+    c3 = q(conv3d(c2, sd["conv3.conv.weight"], bn=_bn(sd, "conv3.bn"), stride=2))
+    c4 = q(conv3d(c3, sd["conv4.conv.weight"], bn=_bn(sd, "conv4.bn")))
+    c5 = q(conv3d(c4, sd["conv5.conv.weight"], bn=_bn(sd, "conv5.bn"), stride=2))
+    c6 = q(conv3d(c5, sd["conv6.conv.weight"], bn=_bn(sd, "conv6.bn")))
+    x = q(c4 + deconv3d(c6, sd["conv7.0.weight"], bn=_bn(sd, "conv7.1")))
+    x = q(c2 + deconv3d(x, sd["conv9.0.weight"], bn=_bn(sd, "conv9.1")))
+    x = q(c0 + deconv3d(x, sd["conv11.0.weight"], bn=_bn(sd, "conv11.1")))
     cost = conv3d(x, sd["prob.weight"], bias=sd["prob.bias"], bn=None, relu=False)
     return cost[0]
 
@@ -176,9 +198,9 @@ def costreg_state(full_state: dict) -> dict:
     return out
 
 
-def depth_infer(features, proj_matrices, depth_values, sd):
+def depth_infer(features, proj_matrices, depth_values, sd, storage="f32"):
     """The whole hot path after FeatureNet for one batch item (models/mvsnet.py:145-218)."""
-    var = variance_volume(features, proj_matrices, depth_values)
-    cost = costreg_forward(var, sd)
+    var = round_storage(variance_volume(features, proj_matrices, depth_values), storage)
+    cost = costreg_forward(var, sd, storage)
     depth, conf, idx = softargmin_conf(cost, depth_values)
     return depth, conf

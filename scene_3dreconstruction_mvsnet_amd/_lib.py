@@ -17,6 +17,24 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVS_LIB_PATH") or os.path.join(_HERE, "csrc", "libmvs_hip.so")
 
 MVS_F32, MVS_F16, MVS_BF16 = 0, 1, 2
+DTYPE_CODES = {"f32": MVS_F32, "f16": MVS_F16, "bf16": MVS_BF16,
+               "float32": MVS_F32, "float16": MVS_F16, "bfloat16": MVS_BF16}
+TORCH_DTYPES = {MVS_F32: torch.float32, MVS_F16: torch.float16, MVS_BF16: torch.bfloat16}
+
+
+def dtype_code(dtype) -> int:
+    """'f32' | 'f16' | 'bf16' | torch dtype | mvs_dtype int -> mvs_dtype int (storage dtype of the
+    private volumes; arithmetic stays fp32)."""
+    if isinstance(dtype, int):
+        if dtype in TORCH_DTYPES:
+            return dtype
+        raise ValueError(f"unknown mvs_dtype {dtype}")
+    if isinstance(dtype, torch.dtype):
+        for code, td in TORCH_DTYPES.items():
+            if td == dtype:
+                return code
+        raise ValueError(f"unsupported storage dtype {dtype}")
+    return DTYPE_CODES[str(dtype)]
 NUM_LAYERS = 11
 ABI_VERSION = 1
 
@@ -171,7 +189,7 @@ def warp_variance(feats, rt, depth_values, workspace, dtype=MVS_F32):
     feats = _dev_f32(feats, "features")
     N, C, h, w = feats.shape
     D = depth_values.shape[0]
-    var = torch.empty((C // 8, D, h, w, 8), dtype=torch.float32, device=feats.device)
+    var = torch.empty((C // 8, D, h, w, 8), dtype=TORCH_DTYPES[dtype], device=feats.device)
     check(load().mvs_warp_variance(feats.data_ptr(), rt.data_ptr(),
                                    _dev_f32(depth_values, "depth_values").data_ptr(),
                                    var.data_ptr(), workspace.data_ptr(), workspace.numel(),
@@ -202,7 +220,7 @@ def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
     else:
         odims = (Di, Hi, Wi)
     oshape = odims if layer == 10 else (co // 8,) + odims + (8,)
-    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    y = torch.empty(oshape, dtype=torch.float32 if layer == 10 else TORCH_DTYPES[dtype], device=x.device)
     if skip is not None and tuple(skip.shape) != tuple(oshape):
         raise RuntimeError(f"layer {layer}: skip shape {tuple(skip.shape)} != {oshape}")
     check(load().mvs_conv_layer(layer, x.data_ptr(), 0 if skip is None else skip.data_ptr(),

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "mvs_internal.h"
+#include "storage.h"
 
 namespace mvs {
 
@@ -280,7 +281,8 @@ constexpr int NPIECE = HZ * HY * HX * 2;
 constexpr int PPT = (NPIECE + 255) / 256;  // 16
 }  // namespace pl
 
-__global__ __launch_bounds__(256, 2) void prob_lds_kernel(const float* __restrict__ x,
+template <int DT>
+__global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict__ x,  // storage DT
                                                           const float* __restrict__ wgt,  // [27][8]
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ y, int D, int H, int W) {
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const float* __restric
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t off = ok ? (((size_t)gz * H + gy) * W + gx) * 8 + half * 4 : 0;
-        const float4 val = *reinterpret_cast<const float4*>(x + off);
-        stg[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 val = St<DT>::load4(x, off);
+        stg[i] = ok ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -350,16 +352,18 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const float* __restric
 }
 
 static int run_prob(const void* x, void* y, const float* wgt, const float* bias, int D, int H, int W,
-                    hipStream_t s) {
+                    int dtype, hipStream_t s) {
     static const bool use_gather = [] {  // MVS_PROB_GATHER=1: the global-gather kernel (A/B runs)
         const char* e = getenv("MVS_PROB_GATHER");
         return e && e[0] == '1';
     }();
-    if (!use_gather) {
+    if (!use_gather || dtype != MVS_F32) {
         using namespace pl;
         const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
-        prob_lds_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), wgt, bias,
-                                           static_cast<float*>(y), D, H, W);
+        float* yo = static_cast<float*>(y);
+        if (dtype == MVS_F32) prob_lds_kernel<MVS_F32><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
+        else if (dtype == MVS_F16) prob_lds_kernel<MVS_F16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
+        else prob_lds_kernel<MVS_BF16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
         return check_hip(hipGetLastError(), "prob_lds launch");
     }
     const size_t nthreads = (size_t)H * W * ((D + kProbZPT - 1) / kProbZPT);
@@ -397,7 +401,7 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
         case 8: return run_direct<32, 16, 16, 2, true, true, true>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 9: return run_deconv<16, 8, 8>(x, skip, y, wgt, bias, Di, Hi, Wi, s);
         case 10:
-            return run_prob(x, y, wgt, bias, Di, Hi, Wi, s);
+            return run_prob(x, y, wgt, bias, Di, Hi, Wi, MVS_F32, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "unknown CostRegNet layer %d", layer);
     }
 }
@@ -413,17 +417,25 @@ static bool force_direct() {
 
 int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* blob,
                       int Di, int Hi, int Wi, int dtype, hipStream_t s) {
-    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "conv3d: dtype %d not implemented", dtype);
     const BlobLayout L = blob_layout();
-    if (layer == 0 && !force_direct())
-        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, s);
-    if (layer >= 1 && layer <= 6 && !force_direct())
-        return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
-    if (layer >= 7 && layer <= 9 && !force_direct())
+    if (force_direct()) {
+        if (dtype != MVS_F32)
+            return fail(MVS_ERR_BAD_DTYPE, "MVS_FORCE_DIRECT kernels are fp32-storage only (dtype %d)", dtype);
+        return launch_conv_layer_direct(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer],
+                                        Di, Hi, Wi, dtype, s);
+    }
+    if (layer == 0)
+        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
+                                 dtype, s);
+    if (layer >= 1 && layer <= 6)
+        return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi,
+                                 dtype, s);
+    if (layer >= 7 && layer <= 9)
         return launch_deconvg_mfma(layer, x, skip, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di,
-                                   Hi, Wi, s);
-    return launch_conv_layer_direct(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer],
-                                    Di, Hi, Wi, dtype, s);
+                                   Hi, Wi, dtype, s);
+    if (layer == 10)
+        return run_prob(x, y, blob + L.w_off[10], blob + L.b_off[10], Di, Hi, Wi, dtype, s);
+    return fail(MVS_ERR_BAD_SHAPE, "unknown CostRegNet layer %d", layer);
 }
 
 }  // namespace mvs

@@ -23,10 +23,10 @@
 #include <cstdlib>
 
 #include "mvs_internal.h"
+#include "storage.h"
 
 namespace mvs {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic builds only (make ABLATE=n -> libmvs_hip_ablate<n>.so, wrong results by design):
 //   1 = conv0 without epilogue stores, 2 = without chunk re-staging, 3 = also without the
@@ -368,11 +368,12 @@ namespace c0 {
 constexpr int BQ_FLOATS = 27 * 2 * 2 * 4 * 4;  // per chunk
 }
 
+template <int DT>
 __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
-    const float* __restrict__ x,     // [4][D][H][W][8]
+    const void* __restrict__ x,      // [4][D][H][W][8] storage dtype DT
     const float* __restrict__ bq,    // [4 chunks][27 taps][2 halves][2 nt][4 j][4 k]
     const float* __restrict__ bias,  // [8]
-    float* __restrict__ y,           // [D][H][W][8]
+    void* __restrict__ y,            // [D][H][W][8] storage dtype DT
     int D, int H, int W) {
     using namespace c0;
     __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + BQ_FLOATS];
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
     constexpr int WPIECES = BQ_FLOATS / 4;  // 432 16-byte pieces of weights per chunk
 #define MVS_LOAD_A(C)                                                                         \
     {                                                                                         \
-        const float* plane = x + (size_t)(C) * V * 8;                                         \
+        const size_t plane = (size_t)(C) * V * 8;                                             \
         _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
-            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                        \
+            stg[i] = St<DT>::load4(x, plane + goff[i]);                                       \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(bq) + (size_t)(C) * WPIECES;       \
         wst[0] = wsrc[tid];                                                                   \
         wst[1] = wsrc[min(tid + 256, WPIECES - 1)];                                           \
@@ -482,9 +483,10 @@ __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
             const int vox = 4 * blk + i;  // 0..63: (row, xl) = (vox >> 5, vox & 31)
             const int gy = y0 + yt0 + 2 * m + (vox >> 5), gx = x0 + (vox & 31);
             if (gz < D && gy < H && gx < W) {
-                float* o = y + (((size_t)gz * H + gy) * W + gx) * 8;
+                const size_t o = (((size_t)gz * H + gy) * W + gx) * 8;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) o[4 * n + j] = fmaxf(acc[m][n][i] + bias[4 * n + j], 0.0f);
+                for (int n = 0; n < 2; ++n)
+                    St<DT>::store1(y, o + 4 * n + j, fmaxf(acc[m][n][i] + bias[4 * n + j], 0.0f));
             }
         }
 }
@@ -501,11 +503,18 @@ void pack_conv0_4x4_weights(const float* wfold, float* bq) {
                                 wfold[((size_t)tap * 32 + 8 * c + 4 * half + k) * 8 + 4 * nt + j];
 }
 
+template <int DT>
+static int run_conv0_4x4(const void* x, void* y, const float* bq, const float* bias, int D, int H, int W,
+                         int nb, hipStream_t s) {
+    conv0_4x4_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bq, bias, y, D, H, W);
+    return check_hip(hipGetLastError(), "conv0_4x4_mfma launch");
+}
+
 int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, const float* bias,
-                      int D, int H, int W, hipStream_t s) {
+                      int D, int H, int W, int dtype, hipStream_t s) {
     using namespace c0;
     if ((size_t)D * H * W * 8 >= ((size_t)1 << 31))
-        return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu floats exceeds 31-bit offsets",
+        return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu elements exceeds 31-bit offsets",
                     (size_t)D * H * W * 8);
     const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
     static const bool eight_waves = [] {  // MVS_CONV0_8W=1: the 512-thread split-K variant (A/B runs;
@@ -516,10 +525,10 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, 
         const char* e = getenv("MVS_CONV0_PAIR");
         return e && e[0] == '1';
     }();
-    if (!pair_kernel && !eight_waves)
-        conv0_4x4_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bq, bias,
-                                                 static_cast<float*>(y), D, H, W);
-    else if (!eight_waves)
+    if (!pair_kernel && !eight_waves) { MVS_DISPATCH_DTYPE(dtype, (run_conv0_4x4<DT>(x, y, bq, bias, D, H, W, nb, s))) }
+    if (dtype != MVS_F32)
+        return fail(MVS_ERR_BAD_DTYPE, "the opt-in conv0 variants are fp32-storage only (dtype %d)", dtype);
+    if (!eight_waves)
         conv0_pair_mfma_kernel<<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
                                                   static_cast<float*>(y), D, H, W);
     else
@@ -567,12 +576,12 @@ struct ConvG {
     }
 };
 
-template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+template <int DT, int CIN, int COUT, int S, int BZ, int BY, int BX>
 __global__ __launch_bounds__(256) void convg_mfma_kernel(
-    const float* __restrict__ x,     // [CIN/8][Di][Hi][Wi][8]
+    const void* __restrict__ x,      // [CIN/8][Di][Hi][Wi][8] storage dtype DT
     const float* __restrict__ bp,    // [NCH][NT][14][64][4]
     const float* __restrict__ bias,  // [COUT]
-    float* __restrict__ y,           // [COUT/8][Do][Ho][Wo][8]
+    void* __restrict__ y,            // [COUT/8][Do][Ho][Wo][8] storage dtype DT
     int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
     using G = ConvG<CIN, COUT, S, BZ, BY, BX>;
     __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
@@ -629,9 +638,9 @@ __global__ __launch_bounds__(256) void convg_mfma_kernel(
     }
 #define MVS_LOAD_A(C)                                                                               \
     {                                                                                               \
-        const float* plane = x + (size_t)(C) * Vin * 8;                                             \
+        const size_t plane = (size_t)(C) * Vin * 8;                                                 \
         _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
-            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                              \
+            stg[i] = St<DT>::load4(x, plane + goff[i]);                                             \
     }
 #define MVS_STORE_A()                                                                               \
     {                                                                                               \
@@ -681,7 +690,7 @@ __global__ __launch_bounds__(256) void convg_mfma_kernel(
     // epilogue: D layout col n = lane&15 -> co = 16 nt + n; row m = 4*(lane>>4) + e -> voxel of tile
     const int n = lane & 15, co = 16 * nt + n;
     const float bv = bias[co];
-    float* yplane = y + (size_t)(co >> 3) * Vout * 8 + (co & 7);
+    const size_t yplane = (size_t)(co >> 3) * Vout * 8 + (co & 7);
 #pragma unroll
     for (int i = 0; i < G::MPW; ++i) {
         const int t = mg * G::MPW + i;
@@ -692,35 +701,41 @@ __global__ __launch_bounds__(256) void convg_mfma_kernel(
             const int m = 4 * (lane >> 4) + e;
             const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
             if (gz < Do && gy < Ho && gx < Wo)
-                yplane[(((size_t)gz * Ho + gy) * Wo + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+                St<DT>::store1(y, yplane + (((size_t)gz * Ho + gy) * Wo + gx) * 8, fmaxf(acc[i][e] + bv, 0.0f));
         }
     }
 }
 
-template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+template <int DT, int CIN, int COUT, int S, int BZ, int BY, int BX>
 static int run_convg(const void* x, void* y, const float* bp, const float* bias, int Di, int Hi, int Wi,
                      hipStream_t s) {
     const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
     if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: plane exceeds 31-bit offsets");
     const int nb = ((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
-    convg_mfma_kernel<CIN, COUT, S, BZ, BY, BX><<<nb, 256, 0, s>>>(
-        static_cast<const float*>(x), bp, bias, static_cast<float*>(y), Di, Hi, Wi, Do, Ho, Wo);
+    convg_mfma_kernel<DT, CIN, COUT, S, BZ, BY, BX><<<nb, 256, 0, s>>>(x, bp, bias, y, Di, Hi, Wi, Do,
+                                                                       Ho, Wo);
     return check_hip(hipGetLastError(), "convg_mfma launch");
+}
+
+template <int DT>
+static int launch_convg_dt(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
+                           int Hi, int Wi, hipStream_t s) {
+    switch (layer) {
+        case 1: return run_convg<DT, 8, 16, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 2: return run_convg<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convg<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 4: return run_convg<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 5: return run_convg<DT, 32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 6: return run_convg<DT, 64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: layer %d not covered", layer);
+    }
 }
 
 // layers 1..6 (conv1..conv6)
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
-                      int Hi, int Wi, hipStream_t s) {
-    switch (layer) {
-        case 1: return run_convg<8, 16, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 2: return run_convg<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 3: return run_convg<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 4: return run_convg<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 5: return run_convg<32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 6: return run_convg<64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
-        default: return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: layer %d not covered", layer);
-    }
+                      int Hi, int Wi, int dtype, hipStream_t s) {
+    MVS_DISPATCH_DTYPE(dtype, (launch_convg_dt<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s)))
 }
 
 // Host-side packing for convg: wfold [27][cin][cout] -> bp [cin/8][cout/16][14][64][4]
@@ -791,13 +806,13 @@ __host__ __device__ constexpr DeconvStep deconv_step(int ks) {
                    : DeconvStep{3, 0, 1, 0, 1};
 }
 
-template <int CIN, int COUT, int BZ, int BY, int BX>
+template <int DT, int CIN, int COUT, int BZ, int BY, int BX>
 __global__ __launch_bounds__(256) void deconvg_mfma_kernel(
-    const float* __restrict__ x,     // [CIN/8][Di][Hi][Wi][8]
+    const void* __restrict__ x,      // [CIN/8][Di][Hi][Wi][8] storage dtype DT
     const float* __restrict__ bp,    // [NCH][NTT][9][64][4]
     const float* __restrict__ bias,  // [COUT]
-    const float* __restrict__ skip,  // [COUT/8][2Di][2Hi][2Wi][8]
-    float* __restrict__ y,           // [COUT/8][2Di][2Hi][2Wi][8]
+    const void* __restrict__ skip,   // [COUT/8][2Di][2Hi][2Wi][8]
+    void* __restrict__ y,            // [COUT/8][2Di][2Hi][2Wi][8]
     int Di, int Hi, int Wi) {
     using G = DeconvG<CIN, COUT, BZ, BY, BX>;
     __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
@@ -855,9 +870,9 @@ __global__ __launch_bounds__(256) void deconvg_mfma_kernel(
     }
 #define MVS_LOAD_A(C)                                                                               \
     {                                                                                               \
-        const float* plane = x + (size_t)(C) * Vin * 8;                                             \
+        const size_t plane = (size_t)(C) * Vin * 8;                                                 \
         _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
-            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                              \
+            stg[i] = St<DT>::load4(x, plane + goff[i]);                                             \
     }
 #define MVS_STORE_A()                                                                               \
     {                                                                                               \
@@ -924,34 +939,38 @@ __global__ __launch_bounds__(256) void deconvg_mfma_kernel(
                 for (int cls = 0; cls < 4; ++cls) {
                     const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
                     const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
-                    y[o] = fmaxf(acc[cls][i][e] + bv, 0.0f) + skip[o];
+                    St<DT>::store1(y, o, fmaxf(acc[cls][i][e] + bv, 0.0f) + St<DT>::load1(skip, o));
                 }
             }
         }
     }
 }
 
-template <int CIN, int COUT, int BZ, int BY, int BX>
+template <int DT, int CIN, int COUT, int BZ, int BY, int BX>
 static int run_deconvg(const void* x, const void* skip, void* y, const float* bp, const float* bias,
                        int Di, int Hi, int Wi, hipStream_t s) {
     if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: plane exceeds 31-bit offsets");
     const int nb = ((Wi + 8 * BX - 1) / (8 * BX)) * ((Hi + 2 * BY - 1) / (2 * BY)) * ((Di + BZ - 1) / BZ);
-    deconvg_mfma_kernel<CIN, COUT, BZ, BY, BX><<<nb, 256, 0, s>>>(
-        static_cast<const float*>(x), bp, bias, static_cast<const float*>(skip),
-        static_cast<float*>(y), Di, Hi, Wi);
+    deconvg_mfma_kernel<DT, CIN, COUT, BZ, BY, BX><<<nb, 256, 0, s>>>(x, bp, bias, skip, y, Di, Hi, Wi);
     return check_hip(hipGetLastError(), "deconvg_mfma launch");
+}
+
+template <int DT>
+static int launch_deconvg_dt(int layer, const void* x, const void* skip, void* y, const float* bp,
+                             const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
+    switch (layer) {
+        case 7: return run_deconvg<DT, 64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 8: return run_deconvg<DT, 32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 9: return run_deconvg<DT, 16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: layer %d not covered", layer);
+    }
 }
 
 // layers 7..9 (conv7, conv9, conv11)
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
-                        const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
-    switch (layer) {
-        case 7: return run_deconvg<64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
-        case 8: return run_deconvg<32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
-        case 9: return run_deconvg<16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
-        default: return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: layer %d not covered", layer);
-    }
+                        const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
+    MVS_DISPATCH_DTYPE(dtype, (launch_deconvg_dt<DT>(layer, x, skip, y, bp, bias, Di, Hi, Wi, s)))
 }
 
 // Host-side packing for deconvg: wfold [27][cin][cout] -> bp [cin/8][2*cout/16][9][64][4]

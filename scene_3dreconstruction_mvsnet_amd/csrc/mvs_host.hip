@@ -29,8 +29,6 @@ int check_hip(hipError_t e, const char* what) {
 static int check_dims(int N, int C, int D, int h, int w, int dtype) {
     if (dtype != MVS_F32 && dtype != MVS_F16 && dtype != MVS_BF16)
         return fail(MVS_ERR_BAD_DTYPE, "unknown dtype %d", dtype);
-    if (dtype != MVS_F32)
-        return fail(MVS_ERR_BAD_DTYPE, "storage dtype %d not implemented yet (fp32 only)", dtype);
     if (N < 1 || N > 64) return fail(MVS_ERR_BAD_SHAPE, "number of views N=%d outside [1,64]", N);
     if (C != kC) return fail(MVS_ERR_BAD_SHAPE, "feature channels C=%d, expected %d", C, kC);
     if (D < 8 || h < 8 || w < 8 || (D % 8) || (h % 8) || (w % 8))
@@ -180,7 +178,8 @@ int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const vo
                    int Di, int Hi, int Wi, int dtype, void* stream) {
     if (!x || !y || !weights_blob) return fail(MVS_ERR_NULL, "mvs_conv_layer: NULL argument");
     if (layer < 0 || layer >= MVS_NUM_LAYERS) return fail(MVS_ERR_BAD_SHAPE, "layer %d outside [0,%d)", layer, MVS_NUM_LAYERS);
-    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "storage dtype %d not implemented yet (fp32 only)", dtype);
+    if (dtype != MVS_F32 && dtype != MVS_F16 && dtype != MVS_BF16)
+        return fail(MVS_ERR_BAD_DTYPE, "unknown dtype %d", dtype);
     const LayerSpec& S = kLayers[layer];
     if (S.kind == kDeconv && !skip) return fail(MVS_ERR_NULL, "layer %d needs its skip tensor", layer);
     if (Di < 1 || Hi < 1 || Wi < 1 || (S.stride == 2 && S.kind == kConv && ((Di | Hi | Wi) & 1)))

@@ -121,14 +121,14 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
 int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y, const float* wgt,
                              const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, const float* bias,
-                      int D, int H, int W, hipStream_t s);
+                      int D, int H, int W, int dtype, hipStream_t s);
 void pack_conv0_pair_weights(const float* wfold, float* bp);
 void pack_conv0_4x4_weights(const float* wfold, float* bq);
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
-                      int Hi, int Wi, hipStream_t s);
+                      int Hi, int Wi, int dtype, hipStream_t s);
 void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
-                        const float* bias, int Di, int Hi, int Wi, hipStream_t s);
+                        const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s);

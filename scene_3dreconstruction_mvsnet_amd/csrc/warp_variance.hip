@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "mvs_internal.h"
+#include "storage.h"
 #include "warp_common.h"
 
 namespace mvs {
@@ -116,10 +117,11 @@ int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
 constexpr int kWarpDepthSlab = 8;
 constexpr int kWarpPixPerBlock = 128;
 
+template <int DT>
 __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restrict__ feats_p,
                                                             const float* __restrict__ rt,
                                                             const float* __restrict__ dv,
-                                                            float* __restrict__ var, int N, int D,
+                                                            void* __restrict__ var, int N, int D,
                                                             int h, int w) {
     const int half = threadIdx.x & 1;
     const int hw = h * w;
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
             m = S[pl].y * inv_n; o.y = fmaf(-m, m, Q[pl].y * inv_n);
             m = S[pl].z * inv_n; o.z = fmaf(-m, m, Q[pl].z * inv_n);
             m = S[pl].w * inv_n; o.w = fmaf(-m, m, Q[pl].w * inv_n);
-            *reinterpret_cast<float4*>(var + ((size_t)pl * V0 + (size_t)d * hw + p) * 8 + 4 * half) = o;
+            St<DT>::store4(var, ((size_t)pl * V0 + (size_t)d * hw + p) * 8 + 4 * half,
+                           (f32x4){o.x, o.y, o.z, o.w});
         }
     }
 }
 
 int launch_warp_variance(const float* feats_p, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s) {
-    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "warp_variance: dtype %d not implemented", dtype);
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
     // MVS_WARP_LDS=1 selects the LDS-staged kernel (warp_variance_lds.hip); the L1-gather kernel
     // below is the default: it is the faster of the two on MI355X so far.
@@ -194,9 +196,12 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
         const char* e = getenv("MVS_WARP_LDS");
         return e && e[0] == '1';
     }();
-    if (use_lds && N <= 64) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
+    if (use_lds && N <= 64 && dtype == MVS_F32) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
     dim3 grid((h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
-    warp_variance_kernel<<<grid, 256, 0, s>>>(feats_p, rt, dv, static_cast<float*>(var), N, D, h, w);
+    if (dtype == MVS_F32) warp_variance_kernel<MVS_F32><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
+    else if (dtype == MVS_F16) warp_variance_kernel<MVS_F16><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
+    else if (dtype == MVS_BF16) warp_variance_kernel<MVS_BF16><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
+    else return fail(MVS_ERR_BAD_DTYPE, "warp_variance: unknown dtype %d", dtype);
     return check_hip(hipGetLastError(), "warp_variance launch");
 }
 

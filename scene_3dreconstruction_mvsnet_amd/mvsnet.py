@@ -96,6 +96,9 @@ class MVSNet(nn.Module):
         if debug:
             warnings.warn("debug visualisation bits (cv2.imshow in the reference, mvsnet.py:111-232) "
                           "are ignored by the MI355X path")
+        # storage dtype of the HIP path's private volumes: "f32" (default, = the reference's fp32
+        # pipeline), "f16" or "bf16" (BASELINE.json configs 4 / 2); arithmetic is always fp32
+        self.storage_dtype = "f32"
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
         if self.refine:
@@ -122,12 +125,12 @@ class MVSNet(nn.Module):
             self._blob_cache[key] = (versions, blob)
             return blob
 
-    def _workspace(self, device, N, D, h, w):
-        key = (device.index, N, D, h, w)
+    def _workspace(self, device, N, D, h, w, dtype):
+        key = (device.index, N, D, h, w, dtype)
         with self._cache_lock:
             ws = self._workspace_cache.get(key)
             if ws is None:
-                ws = _lib.alloc_workspace(N, 32, D, h, w, device)
+                ws = _lib.alloc_workspace(N, 32, D, h, w, device, dtype)
                 self._workspace_cache[key] = ws
             return ws
 
@@ -156,10 +159,11 @@ class MVSNet(nn.Module):
             proj = _lib._dev_f32(proj_matrices.to(device), "proj_matrices")
             dv = _lib._dev_f32(depth_values.to(device), "depth_values")
             blob = self._weights_blob(device)
-            ws = self._workspace(device, N, D, h, w)
+            dt = _lib.dtype_code(self.storage_dtype)
+            ws = self._workspace(device, N, D, h, w, dt)
             depth = torch.empty((B, h, w), dtype=torch.float32, device=device)
             conf = torch.empty((B, h, w), dtype=torch.float32, device=device)
             # steps 2-4 (reference mvsnet.py:145-218): one enqueue per batch item, same stream
             for b in range(B):
-                _lib.depth_infer(feats[b], proj[b], dv[b], blob, ws, depth[b], conf[b])
+                _lib.depth_infer(feats[b], proj[b], dv[b], blob, ws, depth[b], conf[b], dtype=dt)
         return {"depth": depth, "photometric_confidence": conf}
