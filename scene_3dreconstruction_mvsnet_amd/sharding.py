@@ -35,9 +35,14 @@ def gather_maps(local: torch.Tensor, n_units: int, rank: int, world: int, group=
         raise ValueError(f"local has {local.shape[0]} rows, expected {kp}")
     if world == 1:
         return local[:n_units]
-    gathered = torch.empty((world * kp,) + tuple(local.shape[1:]), dtype=local.dtype,
-                           device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    # RCCL (backend "nccl") gathers device tensors directly; gloo has no CUDA all-gather, so a
+    # gloo rehearsal with device tensors stages through the host.
+    stage_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.contiguous().cpu() if stage_host else local.contiguous()
+    gathered = torch.empty((world * kp,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(gathered, src, group=group)
+    if stage_host:
+        gathered = gathered.to(local.device)
     # gathered[r*kp + i] is unit r + i*world
     out = torch.empty((n_units,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):
