@@ -45,7 +45,9 @@ LAYERS = [  # (name, cin, cout, level_in, level_out, kind)
 def stage_costs(N, D, h, w, es=4):
     """Algorithmic bytes / FLOPs per stage per map (SURVEY.md §8 d3 definitions)."""
     V0 = D * h * w
-    costs = {"warp_variance": dict(bytes=N * 32 * h * w * 4 + 32 * V0 * es, flops=0.0)}
+    costs = {"warp_variance": dict(bytes=N * 32 * h * w * 4 + 32 * V0 * es, flops=0.0),
+             # fused warp+variance+conv0: features in, 8-channel conv0 output out, conv0's FLOPs
+             "warp_conv0": dict(bytes=N * 32 * h * w * 4 + 8 * V0 * es, flops=2.0 * 27 * 32 * 8 * V0)}
     for name, ci, co, li, lo, kind in LAYERS:
         vin, vout = V0 >> (3 * li), V0 >> (3 * lo)
         skip = co * vout * es if kind == "deconv" else 0
@@ -68,6 +70,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams to round-robin independent maps over (each has its own workspace)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="staged mode: run warp+variance and conv0 as separate kernels (variance volume "
+                         "materialised) instead of the fused mvs_warp_conv0")
     ap.add_argument("--fused-call", action="store_true",
                     help="time mvs_depth_infer (one C call per map) instead of the staged calls")
     args = ap.parse_args()
@@ -116,7 +121,9 @@ def main():
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
-    stage_names = ["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"]
+    fused = not args.unfused
+    stage_names = (["relative_proj", "warp_conv0"] + [l[0] for l in LAYERS[1:]] + ["softargmin"]) if fused \
+        else (["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"])
     n_ev = len(stage_names) + 1
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(K)]
 
@@ -145,22 +152,32 @@ def main():
         rec(0)
         _lib.check(lib.mvs_relative_proj(proj.data_ptr(), B["rt"].data_ptr(), N, st))
         rec(1)
-        _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
-                                         B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D, h,
-                                         w, dt, st))
-        rec(2)
-        x = B["var"]
-        for li in range(11):
+        ei = 2
+        if fused:
+            _lib.check(lib.mvs_warp_conv0(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
+                                          blob.data_ptr(), B["act"][0].data_ptr(), ws.data_ptr(),
+                                          ws.numel(), N, 32, D, h, w, dt, st))
+            x = B["act"][0]
+            first = 1
+        else:
+            _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
+                                             B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D,
+                                             h, w, dt, st))
+            x = B["var"]
+            first = 0
+        rec(ei)
+        for li in range(first, 11):
             yb = B["cost"] if li == 10 else B["act"][li]
             sk = B["act"][skips[li]].data_ptr() if li in skips else 0
             lvin = LAYERS[li][3]
             _lib.check(lib.mvs_conv_layer(li, x.data_ptr(), sk, yb.data_ptr(), blob.data_ptr(),
                                           D >> lvin, h >> lvin, w >> lvin, dt, st))
             x = yb
-            rec(3 + li)
+            ei += 1
+            rec(ei)
         _lib.check(lib.mvs_softargmin_conf(x.data_ptr(), dv.data_ptr(), out[k, 0].data_ptr(),
                                            out[k, 1].data_ptr(), D, h, w, st))
-        rec(14)
+        rec(ei + 1)
 
     def step_fused(k, ev=None):
         ws = wss[k % S]
@@ -240,7 +257,8 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
                 prof = json.load(f)["kernels"]
-            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel", "warp_variance": "mvs::warp_variance_kernel"}
+            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel", "warp_variance": "mvs::warp_variance_kernel",
+                     "warp_conv0": "mvs::warp_conv0_fused_kernel"}
             ent = prof.get(kname.get(roofline["kernel"], ""))
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
@@ -248,10 +266,13 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
-    path_bytes = sum(c["bytes"] for c in costs.values())
-    path_flops = sum(c["flops"] for c in costs.values())
+    # whole-path totals follow SURVEY.md §8 d3 (layer-by-layer, no fusion credited), independent of
+    # which kernels ran
+    ref_costs = {k: v for k, v in costs.items() if k != "warp_conv0"}
+    path_bytes = sum(c["bytes"] for c in ref_costs.values())
+    path_flops = sum(c["flops"] for c in ref_costs.values())
     stagewise_floor_s = sum(max(c["bytes"] / (HBM_PEAK_GBPS * 1e9),
-                                c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)) for c in costs.values())
+                                c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)) for c in ref_costs.values())
 
     # ---- CPU baseline (rank 0, N=1): the oracle on one full map of the same workload ---------
     cpu_baseline = None
@@ -282,7 +303,8 @@ def main():
                                    "resident in HBM -> depth+confidence)",
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",
-                       "call": "fused mvs_depth_infer" if args.fused_call else "staged C-ABI calls",
+                       "call": "single mvs_depth_infer call" if args.fused_call else "staged C-ABI calls",
+                       "warp_conv0": "fused kernel" if (fused or args.fused_call) else "separate kernels",
                        "streams": S},
             "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),
             "hbm_frac_of_peak": round(path_bytes * maps_per_s / 1e9 / (HBM_PEAK_GBPS * world), 4),

@@ -2,6 +2,7 @@
 // Host-side orchestration only: argument validation, workspace carve-up, weight packing and
 // the per-layer launch sequence of CostRegNet (reference models/mvsnet.py:64-73).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -138,10 +139,11 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
     return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
 }
 
-int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_out,
-                        void* workspace, size_t workspace_bytes, int D, int h, int w, int dtype,
-                        void* stream) {
-    if (!var || !weights_blob || !cost_out || !workspace)
+// CostRegNet from the variance volume, or -- var == NULL -- from an already computed conv0
+// output sitting in the workspace's act[0] region (fused warp+variance+conv0 path).
+static int costreg_impl(const void* var, const void* weights_blob, float* cost_out, void* workspace,
+                        size_t workspace_bytes, int D, int h, int w, int dtype, void* stream) {
+    if (!weights_blob || !cost_out || !workspace)
         return fail(MVS_ERR_NULL, "mvs_costreg_forward: NULL argument");
     if (int st = check_dims(1, kC, D, h, w, dtype)) return st;
     // The activation regions do not depend on N; use N=1 offsets relative to the act[] base so
@@ -161,7 +163,7 @@ int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_o
     };
     // models/mvsnet.py:64-73
     int st;
-    if ((st = run(0, var, nullptr, act(0)))) return st;        // conv0
+    if (var && (st = run(0, var, nullptr, act(0)))) return st;  // conv0 (skipped when act(0) is given)
     if ((st = run(1, act(0), nullptr, act(1)))) return st;     // conv1 (s2)
     if ((st = run(2, act(1), nullptr, act(2)))) return st;     // conv2
     if ((st = run(3, act(2), nullptr, act(3)))) return st;     // conv3 (s2)
@@ -172,6 +174,33 @@ int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_o
     if ((st = run(8, act(7), act(2), act(8)))) return st;      // conv2 + conv9(x)
     if ((st = run(9, act(8), act(0), act(9)))) return st;      // conv0 + conv11(x)
     return run(10, act(9), nullptr, cost_out);                 // prob
+}
+
+int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_out,
+                        void* workspace, size_t workspace_bytes, int D, int h, int w, int dtype,
+                        void* stream) {
+    if (!var) return fail(MVS_ERR_NULL, "mvs_costreg_forward: NULL argument");
+    return costreg_impl(var, weights_blob, cost_out, workspace, workspace_bytes, D, h, w, dtype, stream);
+}
+
+int mvs_warp_conv0(const float* feats, const float* rt, const float* depth_values,
+                   const void* weights_blob, void* conv0_out, void* workspace, size_t workspace_bytes,
+                   int N, int C, int D, int h, int w, int dtype, void* stream) {
+    if (!feats || !depth_values || !weights_blob || !conv0_out || !workspace || (N > 1 && !rt))
+        return fail(MVS_ERR_NULL, "mvs_warp_conv0: NULL argument");
+    if (int st = check_dims(N, C, D, h, w, dtype)) return st;
+    const Workspace W = workspace_layout(N, C, D, h, w, dtype);
+    if (workspace_bytes < W.rt)
+        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", W.rt, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
+    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, s)) return st;
+    const BlobLayout L = blob_layout();
+    const float* blob = static_cast<const float*>(weights_blob);
+    return launch_warp_conv0_fused(feats_t, rt, depth_values, blob + L.c0q_off, blob + L.b_off[0],
+                                   conv0_out, N, D, h, w, dtype, s);
 }
 
 int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
@@ -215,16 +244,28 @@ int mvs_depth_infer(const float* feats, const float* proj, const float* depth_va
     float* cost = reinterpret_cast<float*>(ws + W.cost);
     int st;
     if ((st = mvs_relative_proj(proj, rt, N, stream))) return st;
-    if ((st = mvs_warp_variance(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
-                                h, w, dtype, stream)))
-        return st;
-    // CostRegNet activations live behind the variance volume; hand it the sub-workspace that
+    // CostRegNet activations live behind the variance volume; hand costreg the sub-workspace that
     // starts at act[0] laid out as for N = 1 (same relative offsets).
     const Workspace W1 = workspace_layout(1, C, D, h, w, dtype);
     char* sub = ws + (W.act[0] - W1.act[0]);
-    if ((st = mvs_costreg_forward(var, weights_blob, cost, sub,
-                                  workspace_bytes - (size_t)(sub - ws), D, h, w, dtype, stream)))
-        return st;
+    const size_t sub_bytes = workspace_bytes - (size_t)(sub - ws);
+    // MVS_NO_FUSE=1: materialise the variance volume and run conv0 as its own kernel (A/B runs)
+    static const bool no_fuse = [] {
+        const char* e = getenv("MVS_NO_FUSE");
+        return e && e[0] == '1';
+    }();
+    if (no_fuse) {
+        if ((st = mvs_warp_variance(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
+                                    h, w, dtype, stream)))
+            return st;
+        if ((st = costreg_impl(var, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream))) return st;
+    } else {
+        if ((st = mvs_warp_conv0(feats, rt, depth_values, weights_blob, ws + W.act[0], workspace,
+                                 workspace_bytes, N, C, D, h, w, dtype, stream)))
+            return st;
+        if ((st = costreg_impl(nullptr, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream)))
+            return st;
+    }
     return mvs_softargmin_conf(cost, depth_values, depth_out, conf_out, D, h, w, stream);
 }
 

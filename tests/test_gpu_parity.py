@@ -128,6 +128,40 @@ def test_conv0_mfma_matches_oracle(D, h, w):
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1.0))
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob"])
+def test_fused_warp_conv0_matches_reference(name):
+    """mvs_warp_conv0 (variance never materialised) vs conv0 applied to the reference's variance."""
+    fx = load_fixture(name)
+    sd = costreg_sd(fx)
+    feats, proj, dv = fx["features"][0], fx["proj_matrices"][0], fx["depth_values"][0]
+    N, C, h, w = feats.shape
+    ws = _lib.alloc_workspace(N, C, dv.shape[0], h, w, DEV)
+    y = _lib.warp_conv0(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), blob_for(sd), ws)
+    want = orc.conv3d(fx["variance"][0], sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
+    got = _lib.from_c8(y).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-4 * max(np.abs(want).max(), 1.0))
+
+
+@pytest.mark.parametrize("N,h,w,D", [(3, 8, 8, 8), (4, 24, 40, 32), (2, 16, 24, 56), (5, 40, 72, 24)])
+def test_fused_warp_conv0_matches_unfused(N, h, w, D):
+    """Ragged tiles, several depth segments (D > 24) and view counts: fused == unfused kernels."""
+    feats = synthetic.random_features(N, 32, h, w, seed=7)
+    proj = synthetic.cameras(N, h, w, yaw_deg=1.0)
+    dv = synthetic.depth_values(D)
+    sd = synthetic.random_costreg_state(seed=8)
+    blob = blob_for(sd)
+    ws = _lib.alloc_workspace(N, 32, D, h, w, DEV)
+    rt = _lib.relative_proj(cu(proj))
+    fused = _lib.warp_conv0(cu(feats), rt, cu(dv), blob, ws)
+    unfused = _lib.conv_layer(0, _lib.warp_variance(cu(feats), rt, cu(dv), ws), None, blob)
+    torch.cuda.synchronize()
+    a, b = fused.cpu().numpy(), unfused.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * max(np.abs(b).max(), 1.0))
+    want = orc.conv3d(orc.variance_volume(feats, proj, dv), sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
+    np.testing.assert_allclose(_lib.from_c8(fused).cpu().numpy(), want, rtol=0,
+                               atol=3e-4 * max(np.abs(want).max(), 1.0))
+
+
 @pytest.mark.parametrize("layer", list(range(11)))
 def test_every_layer_matches_oracle(layer):
     """mvs_conv_layer for each CostRegNet layer on random C8-planar input vs the oracle."""
@@ -242,6 +276,9 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
     {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
+    {"MVS_NO_FUSE": "1"},        # separate warp+variance and conv0 kernels inside mvs_depth_infer
+    {"MVS_NO_FUSE": "1", "MVS_WARP_LDS": "1"},
+    {"MVS_NO_FUSE": "1", "MVS_FORCE_DIRECT": "1"},
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each
