@@ -5,12 +5,14 @@
 // writing the 32-channel variance volume to HBM (503 MB written + ~900 MB re-read per map at the
 // quoted config when the two stages run as separate kernels).
 //
-// A block owns an 8(y) x 16(x) pixel tile and marches through ZL depth planes.  Its 8 waves are
-// specialised:
-//   * waves 4-7 (producers) compute the variance of ONE halo plane (10 x 18 voxels x 32 channels)
-//     per step -- bilinear gathers of the N-1 source views from the C8-planar features, sum and
-//     sum of squares in registers, exactly the arithmetic of warp_variance_kernel -- and write it
-//     into a 4-slot LDS ring (zeros outside the volume = conv0's zero padding);
+// A block (1024 threads) owns an 8(y) x 16(x) pixel tile and marches through ZL depth planes.  Its
+// 16 waves are specialised:
+//   * waves 4-15 (producers, 768 threads) compute the variance of ONE halo plane (10 x 18 voxels x
+//     32 channels) per step -- one task = (voxel, channel half, plane pair): bilinear gathers of
+//     the N-1 source views from the C8-planar features, sum and sum of squares in registers,
+//     exactly the arithmetic of warp_variance_kernel -- and write it into a 4-slot LDS ring (zeros
+//     outside the volume = conv0's zero padding); three producer waves per SIMD keep enough
+//     gathers in flight to hide their latency;
 //   * waves 0-3 (consumers) run conv0 for the plane produced three steps earlier on
 //     v_mfma_f32_4x4x1_16b_f32 straight from the ring (planes z-1, z, z+1): wave c takes the
 //     K-chunk of channels 8c..8c+7 (27 taps x 8 channels), the four partial accumulators are
@@ -47,7 +49,7 @@ constexpr int ZL = 24;                    // output planes per block
 __device__ __forceinline__ int fz_vox_off(int v, int half) { return v * 8 + ((half ^ ((v >> 3) & 1)) * 4); }
 
 template <int DT>
-__global__ __launch_bounds__(512) void warp_conv0_fused_kernel(
+__global__ __launch_bounds__(1024) void warp_conv0_fused_kernel(
     const float* __restrict__ feats_p,  // [4][N][h][w][8]
     const float* __restrict__ rt,       // [(N-1)][12]
     const float* __restrict__ dv,       // [D]
@@ -73,14 +75,18 @@ __global__ __launch_bounds__(512) void warp_conv0_fused_kernel(
     const int hw = h * w;
 
     // conv0 weights -> LDS (once per block)
-    for (int i = tid; i < WQ_FLOATS / 4; i += 512)
+    for (int i = tid; i < WQ_FLOATS / 4; i += 1024)
         reinterpret_cast<f32x4*>(wq)[i] = reinterpret_cast<const f32x4*>(bq)[i];
 
     const bool producer = wave >= 4;
 
     // ---------------------------------------------------------------- producer state
-    // task = (halo voxel, half); tasks 0..359 over 256 producer threads -> 2 passes
+    // task = (plane pair, halo voxel, half): 720 tasks over the 768 producer threads
     const int ptid = tid - 256;
+    const int ppair = ptid / (2 * NVOX), prem = ptid - ppair * 2 * NVOX;
+    const int phalf = prem & 1, pv = prem >> 1;
+    const int phy = pv / HX, phx = pv - phy * HX;
+    const bool ptask = producer && ptid < 4 * NVOX;
     // ---------------------------------------------------------------- consumer state
     // lane -> voxel of a 64-voxel M-group: 4 rows x 16 x; M-group mg covers rows 4mg..4mg+3
     const int crow = lane >> 4, cx = lane & 15;
@@ -98,67 +104,61 @@ __global__ __launch_bounds__(512) void warp_conv0_fused_kernel(
             // ---- fill halo plane P = zs - 1 + t into ring slot t & 3
             const int P = zs - 1 + t;
             float* slot = ring + (t & 3) * PLANE_FLOATS;
-            if (t <= nz + 1) {
+            if (t <= nz + 1 && ptask) {
                 const bool zin = P >= 0 && P < D;
                 const float depth = dv[min(max(P, 0), D - 1)];
-#pragma unroll 1
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int task = ptid + pass * 256;
-                    if (task >= 2 * NVOX) break;
-                    const int half = task & 1, v = task >> 1;
-                    const int hy = v / HX, hx = v - hy * HX;
-                    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-                    f32x4 out[4];
+                const int half = phalf, v = pv;
+                const int gy = y0 + phy - 1, gx = x0 + phx - 1;
+                f32x4 out[2];
 #pragma unroll
-                    for (int pl = 0; pl < 4; ++pl) out[pl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (zin && gy >= 0 && gy < h && gx >= 0 && gx < w) {
-                        const int p = gy * w + gx;
-                        float4 S[4], Q[4];
+                for (int q = 0; q < 2; ++q) out[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (zin && gy >= 0 && gy < h && gx >= 0 && gx < w) {
+                    const int p = gy * w + gx;
+                    const float* fpl = feats_p + (size_t)(2 * ppair) * plane_stride + 4 * half;
+                    float4 S[2], Q[2];
 #pragma unroll
-                        for (int pl = 0; pl < 4; ++pl) {
-                            const float4 r = *reinterpret_cast<const float4*>(
-                                feats_p + pl * plane_stride + (size_t)p * 8 + 4 * half);
-                            S[pl] = r;
-                            Q[pl] = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
-                        }
-                        const float fx = (float)gx, fy = (float)gy;
-                        for (int vw = 1; vw < N; ++vw) {
-                            const float* r = rt + (size_t)(vw - 1) * 12;
-                            const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
-                            const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
-                            const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
-                            const Samp sm = make_samp(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w,
-                                                      0, 0, w, h);
-                            const float* f0 = feats_p + (size_t)vw * hw * 8 + 4 * half;
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 r = *reinterpret_cast<const float4*>(fpl + q * plane_stride + (size_t)p * 8);
+                        S[q] = r;
+                        Q[q] = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
+                    }
+                    const float fx = (float)gx, fy = (float)gy;
+                    for (int vw = 1; vw < N; ++vw) {
+                        const float* r = rt + (size_t)(vw - 1) * 12;
+                        const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+                        const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+                        const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+                        const Samp sm = make_samp(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w,
+                                                  0, 0, w, h);
+                        const float* f0 = fpl + (size_t)vw * hw * 8;
 #pragma unroll
-                            for (int pl = 0; pl < 4; ++pl) {
-                                const float* f = f0 + pl * plane_stride;
-                                const float4 a = *reinterpret_cast<const float4*>(f + (size_t)sm.o00 * 8);
-                                const float4 bb = *reinterpret_cast<const float4*>(f + (size_t)sm.o01 * 8);
-                                const float4 c = *reinterpret_cast<const float4*>(f + (size_t)sm.o10 * 8);
-                                const float4 e = *reinterpret_cast<const float4*>(f + (size_t)sm.o11 * 8);
-                                float4 wv;
-                                wv.x = fmaf(a.x, sm.w00, fmaf(bb.x, sm.w01, fmaf(c.x, sm.w10, e.x * sm.w11)));
-                                wv.y = fmaf(a.y, sm.w00, fmaf(bb.y, sm.w01, fmaf(c.y, sm.w10, e.y * sm.w11)));
-                                wv.z = fmaf(a.z, sm.w00, fmaf(bb.z, sm.w01, fmaf(c.z, sm.w10, e.z * sm.w11)));
-                                wv.w = fmaf(a.w, sm.w00, fmaf(bb.w, sm.w01, fmaf(c.w, sm.w10, e.w * sm.w11)));
-                                accum(S[pl], Q[pl], wv);
-                            }
-                        }
-#pragma unroll
-                        for (int pl = 0; pl < 4; ++pl) {
-                            const float4 o = variance4(S[pl], Q[pl], inv_n);
-                            // storage-dtype rounding of the (virtual) variance volume keeps the
-                            // 16-bit modes bit-compatible with the unfused path
-                            if (DT == MVS_F16) out[pl] = (f32x4){(float)(_Float16)o.x, (float)(_Float16)o.y, (float)(_Float16)o.z, (float)(_Float16)o.w};
-                            else if (DT == MVS_BF16) out[pl] = (f32x4){(float)(__bf16)o.x, (float)(__bf16)o.y, (float)(__bf16)o.z, (float)(__bf16)o.w};
-                            else out[pl] = (f32x4){o.x, o.y, o.z, o.w};
+                        for (int q = 0; q < 2; ++q) {
+                            const float* f = f0 + q * plane_stride;
+                            const float4 a = *reinterpret_cast<const float4*>(f + (size_t)sm.o00 * 8);
+                            const float4 bb = *reinterpret_cast<const float4*>(f + (size_t)sm.o01 * 8);
+                            const float4 c = *reinterpret_cast<const float4*>(f + (size_t)sm.o10 * 8);
+                            const float4 e = *reinterpret_cast<const float4*>(f + (size_t)sm.o11 * 8);
+                            float4 wv;
+                            wv.x = fmaf(a.x, sm.w00, fmaf(bb.x, sm.w01, fmaf(c.x, sm.w10, e.x * sm.w11)));
+                            wv.y = fmaf(a.y, sm.w00, fmaf(bb.y, sm.w01, fmaf(c.y, sm.w10, e.y * sm.w11)));
+                            wv.z = fmaf(a.z, sm.w00, fmaf(bb.z, sm.w01, fmaf(c.z, sm.w10, e.z * sm.w11)));
+                            wv.w = fmaf(a.w, sm.w00, fmaf(bb.w, sm.w01, fmaf(c.w, sm.w10, e.w * sm.w11)));
+                            accum(S[q], Q[q], wv);
                         }
                     }
 #pragma unroll
-                    for (int pl = 0; pl < 4; ++pl)
-                        *reinterpret_cast<f32x4*>(slot + pl * NVOX * 8 + fz_vox_off(v, half)) = out[pl];
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 o = variance4(S[q], Q[q], inv_n);
+                        // storage-dtype rounding of the (virtual) variance volume keeps the 16-bit
+                        // modes bit-compatible with the unfused path
+                        if (DT == MVS_F16) out[q] = (f32x4){(float)(_Float16)o.x, (float)(_Float16)o.y, (float)(_Float16)o.z, (float)(_Float16)o.w};
+                        else if (DT == MVS_BF16) out[q] = (f32x4){(float)(__bf16)o.x, (float)(__bf16)o.y, (float)(__bf16)o.z, (float)(__bf16)o.w};
+                        else out[q] = (f32x4){o.x, o.y, o.z, o.w};
+                    }
                 }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    *reinterpret_cast<f32x4*>(slot + (2 * ppair + q) * NVOX * 8 + fz_vox_off(v, half)) = out[q];
             }
         } else if (t >= 3) {
             // ---- conv0 of output plane O = zs + t - 3 from ring planes t-3, t-2, t-1
@@ -167,22 +167,23 @@ __global__ __launch_bounds__(512) void warp_conv0_fused_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* wb = wq + chunk * (27 * 2 * 2 * 4 * 4) + (lane & 3) * 4;
-#pragma unroll
-            for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll 1
+            for (int kz = 0; kz < 3; ++kz) {  // not unrolled: bounds the live LDS reads (128-VGPR budget)
                 const float* pl = ring + ((t - 3 + kz) & 3) * PLANE_FLOATS + chunk * NVOX * 8;
-#pragma unroll
+                const float* wbz = wb + kz * (9 * 2 * 2 * 16);
+#pragma unroll 1
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int tap = (kz * 3 + ky) * 3 + kx;
+                        const int tap9 = ky * 3 + kx;
                         const int v0 = (crow + ky) * HX + cx + kx;   // M-group 0: rows 0..3
                         const int v1 = v0 + 4 * HX;                  // M-group 1: rows 4..7
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
                             const f32x4 a0 = *reinterpret_cast<const f32x4*>(pl + fz_vox_off(v0, half));
                             const f32x4 a1 = *reinterpret_cast<const f32x4*>(pl + fz_vox_off(v1, half));
-                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(wb + ((tap * 2 + half) * 2 + 0) * 16);
-                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(wb + ((tap * 2 + half) * 2 + 1) * 16);
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(wbz + ((tap9 * 2 + half) * 2 + 0) * 16);
+                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(wbz + ((tap9 * 2 + half) * 2 + 1) * 16);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], b0[k], acc[0][0], 0, 0, 0);
@@ -240,7 +241,7 @@ static int run_fused(const float* feats_p, const float* rt, const float* dv, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_conv0_fused_kernel<DT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return check_hip(e, "warp_conv0_fused: hipFuncSetAttribute");
-    warp_conv0_fused_kernel<DT><<<nb, 512, lds_bytes, s>>>(feats_p, rt, dv, bq, bias, y, N, D, h, w);
+    warp_conv0_fused_kernel<DT><<<nb, 1024, lds_bytes, s>>>(feats_p, rt, dv, bq, bias, y, N, D, h, w);
     return check_hip(hipGetLastError(), "warp_conv0_fused launch");
 }
 
