@@ -199,7 +199,7 @@ int mvs_warp_conv0(const float* feats, const float* rt, const float* depth_value
     if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, s)) return st;
     const BlobLayout L = blob_layout();
     const float* blob = static_cast<const float*>(weights_blob);
-    return launch_warp_conv0_fused(feats_t, rt, depth_values, blob + L.c0q_off, blob + L.b_off[0],
+    return launch_warp_conv0_fused(feats_t, rt, depth_values, blob + L.c0p_off, blob + L.b_off[0],
                                    conv0_out, N, D, h, w, dtype, s);
 }
 

@@ -114,7 +114,7 @@ int launch_warp_variance(const float* feats_t, const float* rt, const float* dv,
                          int D, int h, int w, int dtype, hipStream_t s);
 int launch_warp_variance_lds(const float* feats_p, const float* rt, const float* dv, void* var, int N,
                              int D, int h, int w, hipStream_t s);
-int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bq,
+int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bp,
                             const float* bias, void* y, int N, int D, int h, int w, int dtype,
                             hipStream_t s);
 int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,

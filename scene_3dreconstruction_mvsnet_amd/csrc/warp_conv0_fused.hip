@@ -5,24 +5,27 @@
 // writing the 32-channel variance volume to HBM (503 MB written + ~900 MB re-read per map at the
 // quoted config when the two stages run as separate kernels).
 //
-// A block (1024 threads) owns an 8(y) x 16(x) pixel tile and marches through ZL depth planes.  Its
-// 16 waves are specialised:
-//   * waves 4-15 (producers, 768 threads) compute the variance of ONE halo plane (10 x 18 voxels x
-//     32 channels) per step -- one task = (voxel, channel half, plane pair): bilinear gathers of
-//     the N-1 source views from the C8-planar features, sum and sum of squares in registers,
-//     exactly the arithmetic of warp_variance_kernel -- and write it into a 4-slot LDS ring (zeros
-//     outside the volume = conv0's zero padding); three producer waves per SIMD keep enough
-//     gathers in flight to hide their latency;
+// A block (768 threads) owns an 8(y) x 16(x) pixel tile and marches through ZL depth planes.  Its
+// 12 waves are specialised:
+//   * waves 4-11 (producers, 512 threads) compute the variance of ONE halo plane (10 x 18 voxels x
+//     32 channels) per step -- one task = (voxel, channel half, plane pair), 720 tasks in two
+//     passes: bilinear gathers of the N-1 source views from the C8-planar features, sum and sum
+//     of squares in registers, exactly the arithmetic of warp_variance_kernel -- written into a
+//     4-slot LDS ring (zeros outside the volume = conv0's zero padding);
 //   * waves 0-3 (consumers) run conv0 for the plane produced three steps earlier on
-//     v_mfma_f32_4x4x1_16b_f32 straight from the ring (planes z-1, z, z+1): wave c takes the
-//     K-chunk of channels 8c..8c+7 (27 taps x 8 channels), the four partial accumulators are
-//     summed through LDS, then bias + ReLU and the store of the 8-channel output plane.
+//     v_mfma_f32_16x16x4_f32 straight from the ring (planes z-1, z, z+1) in the Toeplitz-pair
+//     formulation of conv3d_mfma.hip (N = 2 x-adjacent outputs x 8 channels): wave c takes the
+//     K-chunk of channels 8c..8c+7 and keeps that chunk's B panel (18 k-steps, 72 VGPRs) in
+//     registers for the whole march; the four partial accumulators are summed through LDS, then
+//     bias + ReLU and the store of the 8-channel output plane.  (The 4x4x1 MFMA form, faster for
+//     the stand-alone conv0, is wrong here: its 8-cycle instructions saturate the SIMD's vector
+//     issue port and starve the producer waves' VALU work.)
 // The gathers load the vector-L1 path and the VALU, conv0 the matrix pipe, so the two halves of
 // the block overlap instead of running back to back; the in-plane halo makes the gather work
 // 1.41x that of the unfused kernel, the depth halo 2/ZL more.
 //
-// LDS: ring 4 x (4 chunks x 180 voxels x 32 B) = 92 KB, conv0 weights 27.6 KB (all chunks, 4x4x1
-// panel layout of conv3d_mfma.hip), reduction buffer 12 KB  ->  one block per CU.
+// LDS: ring 4 x (4 chunks x 180 voxels x 32 B) = 92 KB + reduction buffer 16 KB + 32 KB of B
+// fragments -> one block per CU.
 #include <cstdlib>
 
 #include "mvs_internal.h"
@@ -37,9 +40,12 @@ constexpr int HY = TY + 2, HX = TX + 2;   // halo plane
 constexpr int NVOX = HY * HX;             // 180
 constexpr int PLANE_FLOATS = 4 * NVOX * 8;  // [chunk][voxel][8]
 constexpr int RING = 4;
-constexpr int WQ_FLOATS = 4 * 27 * 2 * 2 * 4 * 4;  // all chunks of the 4x4x1 weight panel
-constexpr int RED_FLOATS = 3 * 4 * 64 * 4;         // partials of consumer waves 1..3: [w][mg*2+nt][lane][4]
-constexpr int LDS_FLOATS = RING * PLANE_FLOATS + WQ_FLOATS + RED_FLOATS;
+constexpr int KS = 18;                             // k-steps of 16 per chunk (36 pair taps x 8 ci / 16)
+constexpr int RED_FLOATS = 4 * 4 * 64 * 4;         // partials of the 4 consumer waves: [w][M-tile][lane][4]
+constexpr int KS_REG = 10;                         // k-steps whose B fragments stay in registers
+constexpr int KS_LDS = KS - KS_REG;                // the rest sit in LDS (register budget: 168 VGPRs)
+constexpr int BL_FLOATS = 4 * KS_LDS * 64 * 4;     // [consumer wave][k-step][lane][4]
+constexpr int LDS_FLOATS = RING * PLANE_FLOATS + RED_FLOATS + BL_FLOATS;
 constexpr int ZL = 24;                    // output planes per block
 }  // namespace fz
 
@@ -49,19 +55,19 @@ constexpr int ZL = 24;                    // output planes per block
 __device__ __forceinline__ int fz_vox_off(int v, int half) { return v * 8 + ((half ^ ((v >> 3) & 1)) * 4); }
 
 template <int DT>
-__global__ __launch_bounds__(1024) void warp_conv0_fused_kernel(
+__global__ __launch_bounds__(768) void warp_conv0_fused_kernel(
     const float* __restrict__ feats_p,  // [4][N][h][w][8]
     const float* __restrict__ rt,       // [(N-1)][12]
     const float* __restrict__ dv,       // [D]
-    const float* __restrict__ bq,       // conv0 4x4x1 panel [4][27][2][2][4][4]
+    const float* __restrict__ bp,       // conv0 Toeplitz-pair panel [4 chunks][18][64 lanes][4]
     const float* __restrict__ bias,     // [8]
     void* __restrict__ y,               // [D][h][w][8] storage dtype DT
     int N, int D, int h, int w) {
     using namespace fz;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ring = lds;
-    float* wq = lds + RING * PLANE_FLOATS;
-    float* red = wq + WQ_FLOATS;
+    float* red = lds + RING * PLANE_FLOATS;
+    float* blds = red + RED_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tilesx = (w + TX - 1) / TX, tilesy = (h + TY - 1) / TY;
@@ -74,40 +80,47 @@ __global__ __launch_bounds__(1024) void warp_conv0_fused_kernel(
     const int nz = ze - zs;
     const int hw = h * w;
 
-    // conv0 weights -> LDS (once per block)
-    for (int i = tid; i < WQ_FLOATS / 4; i += 1024)
-        reinterpret_cast<f32x4*>(wq)[i] = reinterpret_cast<const f32x4*>(bq)[i];
-
     const bool producer = wave >= 4;
 
     // ---------------------------------------------------------------- producer state
-    // task = (plane pair, halo voxel, half): 720 tasks over the 768 producer threads
+    // task = (plane pair, halo voxel, half): 720 tasks over the 512 producer threads, 2 passes
     const int ptid = tid - 256;
-    const int ppair = ptid / (2 * NVOX), prem = ptid - ppair * 2 * NVOX;
-    const int phalf = prem & 1, pv = prem >> 1;
-    const int phy = pv / HX, phx = pv - phy * HX;
-    const bool ptask = producer && ptid < 4 * NVOX;
     // ---------------------------------------------------------------- consumer state
-    // lane -> voxel of a 64-voxel M-group: 4 rows x 16 x; M-group mg covers rows 4mg..4mg+3
-    const int crow = lane >> 4, cx = lane & 15;
+    // A fragment lane (r = lane&15 -> pair (row r>>3, pair r&7) of an M-tile of 2 rows x 8 pairs,
+    // g = lane>>4): k-step ks covers pair-taps 2ks + (g>>1), channels 4(g&1)..+3 of the chunk
+    const int cr = lane & 15, cg = lane >> 4;
+    const int crow = cr >> 3, cxp = 2 * (cr & 7) + (cg >> 1), chalf = cg & 1;
     const int chunk = wave & 3;  // consumer wave c handles channels 8c..8c+7
-    f32x4 acc[2][2];
+    f32x4 breg[KS_REG];          // this wave's B panel, resident for the whole march
+    const f32x4* bl = reinterpret_cast<const f32x4*>(blds) + (size_t)chunk * KS_LDS * 64 + lane;
+    if (!producer) {
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) + (size_t)chunk * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS_REG; ++ks) breg[ks] = bsrc[ks * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS_LDS; ++ks)
+            reinterpret_cast<f32x4*>(blds)[((size_t)chunk * KS_LDS + ks) * 64 + lane] = bsrc[(KS_REG + ks) * 64];
+    }
 
     const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
     const size_t plane_stride = (size_t)N * hw * 8;
     const float inv_n = 1.0f / (float)N;
-
-    __syncthreads();  // weights visible
 
     for (int t = 0; t < nz + 3; ++t) {
         if (producer) {
             // ---- fill halo plane P = zs - 1 + t into ring slot t & 3
             const int P = zs - 1 + t;
             float* slot = ring + (t & 3) * PLANE_FLOATS;
-            if (t <= nz + 1 && ptask) {
-                const bool zin = P >= 0 && P < D;
-                const float depth = dv[min(max(P, 0), D - 1)];
-                const int half = phalf, v = pv;
+            if (t <= nz + 1) {
+              const bool zin = P >= 0 && P < D;
+              const float depth = dv[min(max(P, 0), D - 1)];
+#pragma unroll 1
+              for (int pass = 0; pass < 2; ++pass) {
+                const int task = ptid + pass * 512;
+                if (task >= 4 * NVOX) break;
+                const int ppair = task / (2 * NVOX), prem = task - ppair * 2 * NVOX;
+                const int half = prem & 1, v = prem >> 1;
+                const int phy = v / HX, phx = v - phy * HX;
                 const int gy = y0 + phy - 1, gx = x0 + phx - 1;
                 f32x4 out[2];
 #pragma unroll
@@ -159,80 +172,60 @@ __global__ __launch_bounds__(1024) void warp_conv0_fused_kernel(
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
                     *reinterpret_cast<f32x4*>(slot + (2 * ppair + q) * NVOX * 8 + fz_vox_off(v, half)) = out[q];
+              }
             }
         } else if (t >= 3) {
             // ---- conv0 of output plane O = zs + t - 3 from ring planes t-3, t-2, t-1
+            f32x4 acc[4];  // M-tile i = rows 2i, 2i+1 of the 8 x 16 tile
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* wb = wq + chunk * (27 * 2 * 2 * 4 * 4) + (lane & 3) * 4;
-#pragma unroll 1
-            for (int kz = 0; kz < 3; ++kz) {  // not unrolled: bounds the live LDS reads (128-VGPR budget)
+            for (int ks = 0; ks < KS; ++ks) {
+                const int tap0 = 2 * ks;  // pair taps (kz, ky, kx') with kx' = tap % 4
+                const int kz = tap0 / 12, ky = (tap0 / 4) % 3, kx0 = tap0 % 4;
                 const float* pl = ring + ((t - 3 + kz) & 3) * PLANE_FLOATS + chunk * NVOX * 8;
-                const float* wbz = wb + kz * (9 * 2 * 2 * 16);
-#pragma unroll 1
-                for (int ky = 0; ky < 3; ++ky)
+                f32x4 a[4];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int tap9 = ky * 3 + kx;
-                        const int v0 = (crow + ky) * HX + cx + kx;   // M-group 0: rows 0..3
-                        const int v1 = v0 + 4 * HX;                  // M-group 1: rows 4..7
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(
+                        pl + fz_vox_off((2 * i + crow + ky) * HX + cxp + kx0, chalf));
+                const f32x4 bq = ks < KS_REG ? breg[ks < KS_REG ? ks : 0] : bl[(ks - KS_REG) * 64];
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const f32x4 a0 = *reinterpret_cast<const f32x4*>(pl + fz_vox_off(v0, half));
-                            const f32x4 a1 = *reinterpret_cast<const f32x4*>(pl + fz_vox_off(v1, half));
-                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(wbz + ((tap9 * 2 + half) * 2 + 0) * 16);
-                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(wbz + ((tap9 * 2 + half) * 2 + 1) * 16);
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], b0[k], acc[0][0], 0, 0, 0);
-                                acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], b1[k], acc[0][1], 0, 0, 0);
-                                acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[k], b0[k], acc[1][0], 0, 0, 0);
-                                acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[k], b1[k], acc[1][1], 0, 0, 0);
-                            }
-                        }
-                    }
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
             }
-            if (wave > 0) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        *reinterpret_cast<f32x4*>(red + (((wave - 1) * 4 + m * 2 + n) * 64 + lane) * 4) = acc[m][n];
-            }
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4*>(red + ((wave * 4 + i) * 64 + lane) * 4) = acc[i];
         }
-        __syncthreads();  // plane t & 3 complete; partial sums of waves 1..3 published
-        if (wave == 0 && t >= 3) {
+        __syncthreads();  // plane t & 3 complete; partial sums of the consumer waves published
+        if (t >= 3) {
+            // all threads: sum the four K-chunk partials, bias + ReLU, store.  Element q of the
+            // 4 x 64 x 4 accumulator image = (M-tile i, lane l, register e); D layout: column
+            // n = l&15 = (j, co), row m = 4*(l>>4) + e = pair (row m>>3, pair m&7) of M-tile i.
             const int O = zs + t - 3;
-            const int blk = lane >> 2, j = lane & 3;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    f32x4 s = acc[m][n];
-#pragma unroll
-                    for (int wv = 0; wv < 3; ++wv) {
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((wv * 4 + m * 2 + n) * 64 + lane) * 4);
-                        s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
-                    }
-                    const float bv = bias[4 * n + j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int vox = 4 * blk + i;  // voxel of the M-group: (row, x) = (vox >> 4, vox & 15)
-                        const int gy = y0 + 4 * m + (vox >> 4), gx = x0 + (vox & 15);
-                        if (gy < h && gx < w)
-                            St<DT>::store1(y, (((size_t)O * h + gy) * w + gx) * 8 + 4 * n + j,
-                                           fmaxf(s[i] + bv, 0.0f));
-                    }
-                }
+#pragma unroll 1
+            for (int q = tid; q < 4 * 64 * 4; q += 768) {
+                const float sum = red[q] + red[q + 1024] + red[q + 2048] + red[q + 3072];
+                const int e = q & 3, l = (q >> 2) & 63, i = q >> 8;
+                const int n = l & 15, jj = n >> 3, co = n & 7;
+                const int m = 4 * (l >> 4) + e;
+                const int gy = y0 + 2 * i + (m >> 3), gx = x0 + 2 * (m & 7) + jj;
+                if (gy < h && gx < w)
+                    St<DT>::store1(y, (((size_t)O * h + gy) * w + gx) * 8 + co, fmaxf(sum + bias[co], 0.0f));
+            }
         }
         __syncthreads();  // reduction buffer and ring slot (t+1)&3 free again
     }
 }
 
 template <int DT>
-static int run_fused(const float* feats_p, const float* rt, const float* dv, const float* bq,
+static int run_fused(const float* feats_p, const float* rt, const float* dv, const float* bp,
                      const float* bias, void* y, int N, int D, int h, int w, hipStream_t s) {
     using namespace fz;
     const int nb = ((w + TX - 1) / TX) * ((h + TY - 1) / TY) * ((D + ZL - 1) / ZL);
@@ -241,15 +234,15 @@ static int run_fused(const float* feats_p, const float* rt, const float* dv, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_conv0_fused_kernel<DT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return check_hip(e, "warp_conv0_fused: hipFuncSetAttribute");
-    warp_conv0_fused_kernel<DT><<<nb, 1024, lds_bytes, s>>>(feats_p, rt, dv, bq, bias, y, N, D, h, w);
+    warp_conv0_fused_kernel<DT><<<nb, 768, lds_bytes, s>>>(feats_p, rt, dv, bp, bias, y, N, D, h, w);
     return check_hip(hipGetLastError(), "warp_conv0_fused launch");
 }
 
-int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bq,
+int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bp,
                             const float* bias, void* y, int N, int D, int h, int w, int dtype,
                             hipStream_t s) {
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_conv0_fused: h,w must be >= 2");
-    MVS_DISPATCH_DTYPE(dtype, (run_fused<DT>(feats_p, rt, dv, bq, bias, y, N, D, h, w, s)))
+    MVS_DISPATCH_DTYPE(dtype, (run_fused<DT>(feats_p, rt, dv, bp, bias, y, N, D, h, w, s)))
 }
 
 }  // namespace mvs
