@@ -70,9 +70,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams to round-robin independent maps over (each has its own workspace)")
-    ap.add_argument("--unfused", action="store_true",
-                    help="staged mode: run warp+variance and conv0 as separate kernels (variance volume "
-                         "materialised) instead of the fused mvs_warp_conv0")
+    ap.add_argument("--fused-conv0", action="store_true",
+                    help="staged mode: use the fused mvs_warp_conv0 kernel (variance volume never "
+                         "materialised) instead of separate warp+variance and conv0 kernels")
     ap.add_argument("--fused-call", action="store_true",
                     help="time mvs_depth_infer (one C call per map) instead of the staged calls")
     args = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
-    fused = not args.unfused
+    fused = args.fused_conv0
     stage_names = (["relative_proj", "warp_conv0"] + [l[0] for l in LAYERS[1:]] + ["softargmin"]) if fused \
         else (["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"])
     n_ev = len(stage_names) + 1
@@ -304,7 +304,7 @@ def main():
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",
                        "call": "single mvs_depth_infer call" if args.fused_call else "staged C-ABI calls",
-                       "warp_conv0": "fused kernel" if (fused or args.fused_call) else "separate kernels",
+                       "warp_conv0": "fused kernel" if (fused or os.environ.get("MVS_FUSE") == "1") else "separate kernels",
                        "streams": S},
             "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),
             "hbm_frac_of_peak": round(path_bytes * maps_per_s / 1e9 / (HBM_PEAK_GBPS * world), 4),

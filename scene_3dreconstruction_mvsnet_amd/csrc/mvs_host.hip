@@ -249,10 +249,12 @@ int mvs_depth_infer(const float* feats, const float* proj, const float* depth_va
     const Workspace W1 = workspace_layout(1, C, D, h, w, dtype);
     char* sub = ws + (W.act[0] - W1.act[0]);
     const size_t sub_bytes = workspace_bytes - (size_t)(sub - ws);
-    // MVS_NO_FUSE=1: materialise the variance volume and run conv0 as its own kernel (A/B runs)
+    // Default: materialise the variance volume and run conv0 as its own kernel -- on MI355X the two
+    // separate kernels (0.29 + 0.57 ms at cfg2) beat the fused kernel (1.40 ms: one block per CU
+    // cannot keep enough gathers in flight).  MVS_FUSE=1 selects the fused path.
     static const bool no_fuse = [] {
-        const char* e = getenv("MVS_NO_FUSE");
-        return e && e[0] == '1';
+        const char* e = getenv("MVS_FUSE");
+        return !(e && e[0] == '1');
     }();
     if (no_fuse) {
         if ((st = mvs_warp_variance(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,

@@ -276,9 +276,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
     {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
-    {"MVS_NO_FUSE": "1"},        # separate warp+variance and conv0 kernels inside mvs_depth_infer
-    {"MVS_NO_FUSE": "1", "MVS_WARP_LDS": "1"},
-    {"MVS_NO_FUSE": "1", "MVS_FORCE_DIRECT": "1"},
+    {"MVS_FUSE": "1"},           # fused warp+variance+conv0 kernel inside mvs_depth_infer
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each
