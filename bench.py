@@ -257,8 +257,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
                 prof = json.load(f)["kernels"]
-            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel", "warp_variance": "mvs::warp_variance_kernel",
-                     "warp_conv0": "mvs::warp_conv0_fused_kernel"}
+            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel<0>", "warp_variance": "mvs::warp_variance_kernel<0>"}
             ent = prof.get(kname.get(roofline["kernel"], ""))
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
