@@ -24,26 +24,31 @@ from . import _lib
 from .module import ConvBnReLU, ConvBnReLU3D
 
 
+# (in, out, kernel, stride, pad) of the 2D feature extractor's ConvBnReLU blocks conv0..conv6
+_FEATURE_BLOCKS = ((3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1),
+                   (16, 16, 3, 1, 1), (16, 32, 5, 2, 2), (32, 32, 3, 1, 1))
+# (in, out, stride) of CostRegNet's ConvBnReLU3D blocks conv0..conv6 and (in, out) of its
+# ConvTranspose3d+BN+ReLU blocks conv7/conv9/conv11 -- the same table as csrc/mvs_internal.h
+_COSTREG_CONVS = ((32, 8, 1), (8, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 64, 2), (64, 64, 1))
+_COSTREG_DECONVS = (("conv7", 64, 32), ("conv9", 32, 16), ("conv11", 16, 8))
+
+
 class FeatureNet(nn.Module):
-    """2D feature extractor, unchanged torch ops (reference models/mvsnet.py:10-30)."""
+    """2D feature extractor, unchanged torch ops (reference models/mvsnet.py:10-30): seven
+    ConvBnReLU blocks (two of them 5x5 stride 2 -> 1/4 resolution) and a biased 3x3 conv to 32
+    channels; sub-module names conv0..conv6 / feature fix the checkpoint keys."""
 
     def __init__(self):
         super().__init__()
         self.inplanes = 32
-        self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)
-        self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)
-        self.conv2 = ConvBnReLU(8, 16, 5, 2, 2)
-        self.conv3 = ConvBnReLU(16, 16, 3, 1, 1)
-        self.conv4 = ConvBnReLU(16, 16, 3, 1, 1)
-        self.conv5 = ConvBnReLU(16, 32, 5, 2, 2)
-        self.conv6 = ConvBnReLU(32, 32, 3, 1, 1)
+        for i, spec in enumerate(_FEATURE_BLOCKS):
+            setattr(self, f"conv{i}", ConvBnReLU(*spec))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
 
     def forward(self, x):
-        x = self.conv1(self.conv0(x))
-        x = self.conv4(self.conv3(self.conv2(x)))
-        x = self.feature(self.conv6(self.conv5(x)))
-        return x
+        for i in range(len(_FEATURE_BLOCKS)):
+            x = getattr(self, f"conv{i}")(x)
+        return self.feature(x)
 
 
 class CostRegNet(nn.Module):
@@ -51,22 +56,13 @@ class CostRegNet(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.conv0 = ConvBnReLU3D(32, 8)
-        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
-        self.conv2 = ConvBnReLU3D(16, 16)
-        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
-        self.conv4 = ConvBnReLU3D(32, 32)
-        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
-        self.conv6 = ConvBnReLU3D(64, 64)
-        self.conv7 = nn.Sequential(
-            nn.ConvTranspose3d(64, 32, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
-            nn.BatchNorm3d(32), nn.ReLU(inplace=True))
-        self.conv9 = nn.Sequential(
-            nn.ConvTranspose3d(32, 16, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
-            nn.BatchNorm3d(16), nn.ReLU(inplace=True))
-        self.conv11 = nn.Sequential(
-            nn.ConvTranspose3d(16, 8, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
-            nn.BatchNorm3d(8), nn.ReLU(inplace=True))
+        for i, (cin, cout, stride) in enumerate(_COSTREG_CONVS):
+            setattr(self, f"conv{i}", ConvBnReLU3D(cin, cout, stride=stride))
+        for name, cin, cout in _COSTREG_DECONVS:
+            setattr(self, name, nn.Sequential(
+                nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2,
+                                   bias=False),
+                nn.BatchNorm3d(cout), nn.ReLU(inplace=True)))
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
 
     def forward(self, x):  # pragma: no cover - never called on the product path
