@@ -231,6 +231,10 @@ def main():
                 ent["GBps"] = round(c["bytes"] / ms / 1e6, 1)
                 if c["flops"]:
                     ent["TFLOPs"] = round(c["flops"] / ms / 1e9, 2)
+                # fraction of this stage's own roofline: max(HBM time, fp32-MFMA time) / measured
+                floor_ms = max(c["bytes"] / (HBM_PEAK_GBPS * 1e6), c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e9))
+                ent["bound"] = "mfma" if c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e9) > c["bytes"] / (HBM_PEAK_GBPS * 1e6) else "hbm"
+                ent["frac"] = round(floor_ms / ms, 3)
             stages[name] = ent
     roofline = None
     if stages:

@@ -19,6 +19,10 @@
 #include "storage.h"
 #include "warp_common.h"
 
+#ifndef MVS_ABLATE
+#define MVS_ABLATE 0
+#endif
+
 namespace mvs {
 
 // ---------------------------------------------------------------------------------------------
@@ -158,10 +162,15 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
 #pragma unroll
             for (int pl = 0; pl < 4; ++pl) {
                 const float* f = f0 + pl * plane_stride;
+#if MVS_ABLATE == 4  // diagnostic build: no gathers (timing floor of VALU + volume write)
+                (void)f;
+                const float4 a = ref[pl], b = ref[pl], c = ref[pl], e = ref[pl];
+#else
                 const float4 a = *reinterpret_cast<const float4*>(f + (size_t)t.o00 * 8);
                 const float4 b = *reinterpret_cast<const float4*>(f + (size_t)t.o01 * 8);
                 const float4 c = *reinterpret_cast<const float4*>(f + (size_t)t.o10 * 8);
                 const float4 e = *reinterpret_cast<const float4*>(f + (size_t)t.o11 * 8);
+#endif
                 float4 wv;
                 wv.x = fmaf(a.x, t.w00, fmaf(b.x, t.w01, fmaf(c.x, t.w10, e.x * t.w11)));
                 wv.y = fmaf(a.y, t.w00, fmaf(b.y, t.w01, fmaf(c.y, t.w10, e.y * t.w11)));
