@@ -104,6 +104,20 @@ class MVSNet(nn.Module):
         self._blob_cache = {}       # device index -> (param versions, device blob tensor)
         self._workspace_cache = {}  # (device index, N, D, h, w) -> uint8 device tensor
 
+    # The lock and the device caches are process-local: drop them when the module is pickled or
+    # deep-copied (torch.save(model), copy.deepcopy) and start the copy with empty caches.
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_cache_lock", "_blob_cache", "_workspace_cache"):
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._cache_lock = threading.Lock()
+        self._blob_cache = {}
+        self._workspace_cache = {}
+
     # -- caches ------------------------------------------------------------------------------
     def _param_versions(self):
         cr = self.cost_regularization

@@ -161,3 +161,16 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmvs_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.load()
+
+
+def test_module_survives_deepcopy_and_pickle():
+    import copy
+    import io
+    m = MVSNet(refine=False)
+    m2 = copy.deepcopy(m)
+    assert set(m2.state_dict()) == set(m.state_dict()) and m2._blob_cache == {}
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert isinstance(m3, MVSNet) and m3._workspace_cache == {}
