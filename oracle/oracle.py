@@ -152,12 +152,52 @@ def round_storage(a, storage="f32"):
     raise ValueError(storage)
 
 
-def costreg_forward(var, sd, storage="f32"):
+def _fold(sd, wkey, bnprefix, transposed=False):
+    """BN-folded weights in Conv3d layout [Cout,Cin,3,3,3] and the folded bias (as mvs_pack_weights)."""
+    w = np.asarray(sd[wkey], np.float32)
+    if transposed:
+        w = np.ascontiguousarray(w.transpose(1, 0, 2, 3, 4))
+    g, b, m, v = [np.asarray(t, np.float32) for t in _bn(sd, bnprefix)]
+    scale = (g / np.sqrt(v + np.float32(1e-5))).astype(np.float32)
+    shift = (b - m * scale).astype(np.float32)
+    return (w * scale[:, None, None, None, None]).astype(np.float32), shift
+
+
+def costreg_forward_arith16(var, sd, storage):
+    """CostRegNet with 16-bit MFMA operands (conv3d_mfma16.hip): BN-folded weights rounded to the
+    storage dtype, activations stored in it, fp32 accumulation, fp32 bias/ReLU/skip."""
+    q = lambda t: round_storage(t, storage)  # noqa: E731
+
+    def conv(x, i, stride=1):
+        w, sh = _fold(sd, f"conv{i}.conv.weight", f"conv{i}.bn")
+        return q(conv3d(x, q(w), bias=sh, bn=None, stride=stride, relu=True))
+
+    def deconv(x, name, skip):
+        w, sh = _fold(sd, f"{name}.0.weight", f"{name}.1", transposed=True)  # [Cout,Cin,...]
+        wt = np.ascontiguousarray(q(w).transpose(1, 0, 2, 3, 4))              # back to [Cin,Cout,...]
+        y = deconv3d(x, wt, bn=None, relu=False) + sh[:, None, None, None]
+        return q(skip + np.maximum(y, 0.0))
+
+    c0 = conv(var, 0)
+    c2 = conv(conv(c0, 1, 2), 2)
+    c4 = conv(conv(c2, 3, 2), 4)
+    x = conv(conv(c4, 5, 2), 6)
+    x = deconv(x, "conv7", c4)
+    x = deconv(x, "conv9", c2)
+    x = deconv(x, "conv11", c0)
+    cost = conv3d(x, sd["prob.weight"], bias=sd["prob.bias"], bn=None, relu=False)
+    return cost[0]
+
+
+def costreg_forward(var, sd, storage="f32", arith16=False):
     """CostRegNet.forward (models/mvsnet.py:64-73): var [32,D,h,w] -> cost [D,h,w].
 
     `sd` maps reference parameter names *relative to cost_regularization* to numpy arrays.
     `storage` != "f32" rounds every stored activation (see round_storage); logits stay fp32.
+    `arith16` additionally rounds the BN-folded weights (the HIP path's 16-bit MFMA mode).
     """
+    if arith16 and storage not in ("f32", None):
+        return costreg_forward_arith16(var, sd, storage)
     q = lambda t: round_storage(t, storage)  # noqa: E731
     c0 = q(conv3d(var, sd["conv0.conv.weight"], bn=_bn(sd, "conv0.bn")))
     c1 = q(conv3d(c0, sd["conv1.conv.weight"], bn=_bn(sd, "conv1.bn"), stride=2))
@@ -198,9 +238,10 @@ def costreg_state(full_state: dict) -> dict:
     return out
 
 
-def depth_infer(features, proj_matrices, depth_values, sd, storage="f32"):
-    """The whole hot path after FeatureNet for one batch item (models/mvsnet.py:145-218)."""
+def depth_infer(features, proj_matrices, depth_values, sd, storage="f32", arith16=True):
+    """The whole hot path after FeatureNet for one batch item (models/mvsnet.py:145-218).
+    With 16-bit storage the default matches the HIP path's default (16-bit MFMA operands)."""
     var = round_storage(variance_volume(features, proj_matrices, depth_values), storage)
-    cost = costreg_forward(var, sd, storage)
+    cost = costreg_forward(var, sd, storage, arith16=arith16)
     depth, conf, idx = softargmin_conf(cost, depth_values)
     return depth, conf

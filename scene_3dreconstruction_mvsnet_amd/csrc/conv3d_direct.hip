@@ -424,6 +424,15 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         return launch_conv_layer_direct(layer, x, skip, y, blob + L.w_off[layer], blob + L.b_off[layer],
                                         Di, Hi, Wi, dtype, s);
     }
+    // 16-bit storage: 16-bit MFMA arithmetic (conv3d_mfma16.hip) unless MVS_MFMA16=0 asks for fp32
+    // arithmetic on the narrowed operands
+    static const bool mfma16 = [] {
+        const char* e = getenv("MVS_MFMA16");
+        return !(e && e[0] == '0');
+    }();
+    if (mfma16 && (dtype == MVS_F16 || dtype == MVS_BF16) && layer <= 9)
+        return launch_layer_mfma16(layer, x, skip, y, blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][layer],
+                                   blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     if (layer == 0)
         return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
                                  dtype, s);

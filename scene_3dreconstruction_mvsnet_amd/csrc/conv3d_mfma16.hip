@@ -1,0 +1,621 @@
+// conv3d_mfma16.hip -- 16-bit MFMA convolutions for the fp16 / bf16 storage modes (gfx950).
+//
+// When the private volumes are stored in fp16 or bf16 (mvs_dtype MVS_F16 / MVS_BF16; BASELINE.json
+// configs 4 / 2) the CostRegNet convolutions (reference models/mvsnet.py:35-73) run on
+// v_mfma_f32_16x16x32_{f16,bf16}: operands are the stored 16-bit activations and BN-folded weights
+// rounded (RNE) to the same 16-bit type, products are exact and accumulation is fp32.  That is
+// 16x the fp32 MFMA rate, which turns these layers from MFMA-bound into HBM/LDS-bound.
+// (MVS_MFMA16=0 keeps fp32 arithmetic on 16-bit storage: conv3d_mfma.hip.)
+//
+// The C8-planar layout makes the operand mapping trivial: one voxel of one plane is 8 channels =
+// 16 bytes = exactly one lane's A fragment (k = 8*(lane>>4) + j  <->  tap (lane>>4), channel j), so
+// a k-step of 32 is 4 taps x 8 channels and the halo tile is staged and read as raw 16-byte pieces.
+//   convg16   : conv1..conv6, taps padded 27 -> 28 = 7 k-steps per 8-channel chunk
+//   conv0p16  : conv0 in the Toeplitz-pair form (N = 2 x-outputs x 8 channels): the 4 x-taps of a
+//               pair at fixed (kz, ky) are one k-step, 9 per chunk
+//   deconvg16 : conv7/9/11, (z,y) parity classes with the x parity folded into N; 5 k-steps per chunk
+#include <cstdlib>
+#include <cstring>
+
+#include "mvs_internal.h"
+#include "storage.h"
+
+namespace mvs {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    if (DT == MVS_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: fp32 -> 16-bit (RNE) for the weight panels
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t to_bits16(float v, int dt) {
+    uint16_t out;
+    if (dt == MVS_F16) {
+        const _Float16 h = (_Float16)v;
+        std::memcpy(&out, &h, 2);
+    } else {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);  // NaN
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        out = (uint16_t)(u >> 16);
+    }
+    return out;
+}
+
+// =============================================================================================
+// convg16: conv1..conv6
+// =============================================================================================
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+struct ConvG16 {
+    static constexpr int NT = COUT / 16;
+    static constexpr int MG = 4 / NT;
+    static constexpr int MT = BZ * BY * BX;
+    static constexpr int MPW = MT / MG;
+    static constexpr int NCH = CIN / 8;
+    static constexpr int KS = 7;
+    static constexpr int VS = 8;  // 16-bit elements per voxel of a chunk plane (16 B)
+    static constexpr int HZ = (BZ - 1) * S + 3, HY = (2 * BY - 1) * S + 3, HX = (8 * BX - 1) * S + 3;
+    static constexpr int HXP = ((HX + 7) / 8 * 8) | 8;  // row pitch: odd multiple of 8 voxels
+    static constexpr int TILE_ELEMS = HZ * HY * HXP * VS;
+    static constexpr int NPIECE = HZ * HY * HX;  // 16-byte pieces (one voxel each)
+    static constexpr int PPT = (NPIECE + 255) / 256;
+    static_assert(NT == 1 || NT == 2 || NT == 4, "COUT must be 16, 32 or 64");
+    static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
+    static_assert(PPT <= 32, "piece mask is 32 bits");
+    static constexpr int tap_off(int tap) {
+        const int t = tap > 26 ? 26 : tap;
+        return (((t / 9) * HY + (t / 3) % 3) * HXP + t % 3) * VS;
+    }
+};
+
+template <int DT, int CIN, int COUT, int S, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void convg16_mfma_kernel(
+    const void* __restrict__ x,               // [CIN/8][Di][Hi][Wi][8] 16-bit
+    const unsigned short* __restrict__ bp,    // [NCH][NT][7][64][8] 16-bit
+    const float* __restrict__ bias,           // [COUT]
+    void* __restrict__ y,                     // [COUT/8][Do][Ho][Wo][8] 16-bit
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+    using G = ConvG16<CIN, COUT, S, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[G::TILE_ELEMS];
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NT, mg = wave / G::NT;
+    const int nbx = (Wo + 8 * BX - 1) / (8 * BX), nby = (Ho + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ox0 = bx * 8 * BX, oy0 = by * 2 * BY, oz0 = bz * BZ;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = (size_t)Do * Ho * Wo;
+
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int v = tid + i * 256;
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = v < G::NPIECE && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (v < G::NPIECE) ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS : -1;
+    }
+
+    // A fragment: lane (r = lane&15 -> voxel (ry, rx) of the M-tile, g = lane>>4 -> tap 4ks+g)
+    const int r = lane & 15, g = lane >> 4;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = (((tz * S) * G::HY + (2 * ty + ry) * S) * G::HXP + (8 * tx + rx) * S) * G::VS;
+    }
+    int koff[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+        koff[ks] = g == 0 ? G::tap_off(4 * ks) : g == 1 ? G::tap_off(4 * ks + 1)
+                 : g == 2 ? G::tap_off(4 * ks + 2) : G::tap_off(4 * ks + 3);
+
+    f32x4 acc[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 breg[G::KS];
+    u32x4 stg[G::PPT];
+
+#define MVS_LOAD_B(C)                                                                               \
+    {                                                                                               \
+        const u32x4* bsrc =                                                                         \
+            reinterpret_cast<const u32x4*>(bp) + ((size_t)((C) * G::NT + nt) * G::KS) * 64 + lane;  \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];              \
+    }
+#define MVS_LOAD_A(C)                                                                               \
+    {                                                                                               \
+        const unsigned short* plane = xs + (size_t)(C) * Vin * 8;                                   \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            stg[i] = *reinterpret_cast<const u32x4*>(plane + goff[i]);                              \
+    }
+#define MVS_STORE_A()                                                                               \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            if (loff[i] >= 0)                                                                       \
+                *reinterpret_cast<u32x4*>(tile + loff[i]) =                                         \
+                    ((inside >> i) & 1u) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};                        \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(tile + abase[i] + koff[ks]);
+                acc[i] = mfma16<DT>(a, breg[ks], acc[i]);
+            }
+        }
+        if (c + 1 < G::NCH) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    const int n = lane & 15, co = 16 * nt + n;
+    const float bv = bias[co];
+    const size_t yplane = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = oz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
+            if (gz < Do && gy < Ho && gx < Wo)
+                St<DT>::store1(y, yplane + (((size_t)gz * Ho + gy) * Wo + gx) * 8, fmaxf(acc[i][e] + bv, 0.0f));
+        }
+    }
+}
+
+template <int DT, int CIN, int COUT, int S, int BZ, int BY, int BX>
+static int run_convg16(const void* x, void* y, const unsigned short* bp, const float* bias, int Di, int Hi,
+                       int Wi, hipStream_t s) {
+    const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "convg16_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
+    convg16_mfma_kernel<DT, CIN, COUT, S, BZ, BY, BX><<<nb, 256, 0, s>>>(x, bp, bias, y, Di, Hi, Wi, Do,
+                                                                         Ho, Wo);
+    return check_hip(hipGetLastError(), "convg16_mfma launch");
+}
+
+template <int DT>
+static int launch_convg16_dt(int layer, const void* x, void* y, const unsigned short* bp, const float* bias,
+                             int Di, int Hi, int Wi, hipStream_t s) {
+    switch (layer) {
+        case 1: return run_convg16<DT, 8, 16, 2, 2, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 2: return run_convg16<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convg16<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 4: return run_convg16<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 5: return run_convg16<DT, 32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 6: return run_convg16<DT, 64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "convg16_mfma: layer %d not covered", layer);
+    }
+}
+
+// wfold [27][cin][cout] -> bp [cin/8][cout/16][7][64][8] (16-bit)
+void pack_convg16_weights(const float* wfold, int cin, int cout, int dt, unsigned short* bp) {
+    const int nch = cin / 8, nt = cout / 16;
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < nt; ++t)
+            for (int ks = 0; ks < 7; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int g = lane >> 4, n = lane & 15;
+                        const int tap = 4 * ks + g, ci = 8 * c + j, co = 16 * t + n;
+                        const float v = tap < 27 ? wfold[((size_t)tap * cin + ci) * cout + co] : 0.0f;
+                        bp[((((size_t)c * nt + t) * 7 + ks) * 64 + lane) * 8 + j] = to_bits16(v, dt);
+                    }
+}
+
+// =============================================================================================
+// conv0p16: conv0 (32 -> 8) in the Toeplitz-pair form
+// =============================================================================================
+namespace c16 {
+constexpr int TZ = 2, TY = 8, TX = 32;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+constexpr int VS = 8;
+constexpr int TILE_ELEMS = HZ * HY * HX * VS;
+constexpr int NPIECE = HZ * HY * HX;             // 1360
+constexpr int PPT = (NPIECE + 255) / 256;        // 6
+constexpr int KS = 9;                            // (kz, ky) pairs; the 4 x-taps of a pair = one k-step
+}  // namespace c16
+
+template <int DT>
+__global__ __launch_bounds__(256) void conv0p16_mfma_kernel(
+    const void* __restrict__ x,             // [4][D][H][W][8] 16-bit
+    const unsigned short* __restrict__ bp,  // [4 chunks][9][64][8] 16-bit Toeplitz panel
+    const float* __restrict__ bias,         // [8]
+    void* __restrict__ y,                   // [D][H][W][8] 16-bit
+    int D, int H, int W) {
+    using namespace c16;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[TILE_ELEMS];
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const size_t V = (size_t)D * H * W;
+
+    int goff[PPT], loff[PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int v = tid + i * 256;
+        const int hx = v % HX, t = v / HX;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = v < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (int)((((size_t)gz * H + gy) * W + gx) * 8) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (v < NPIECE) ? v * VS : -1;
+    }
+
+    // lane (r = pair index, g = kx' in 0..3): halo x = 2r + g
+    const int r = lane & 15, g = lane >> 4;
+    const int zt = wave >> 1, yt0 = 4 * (wave & 1);
+    const unsigned short* abase = tile + ((zt * HY + yt0) * HX + 2 * r + g) * VS;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 breg[KS];
+    u32x4 stg[PPT];
+
+#define MVS_LOAD_B(C)                                                                         \
+    {                                                                                         \
+        const u32x4* bsrc = reinterpret_cast<const u32x4*>(bp) + (size_t)(C) * KS * 64 + lane; \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) breg[ks] = bsrc[ks * 64];           \
+    }
+#define MVS_LOAD_A(C)                                                                         \
+    {                                                                                         \
+        const unsigned short* plane = xs + (size_t)(C) * V * 8;                               \
+        _Pragma("unroll") for (int i = 0; i < PPT; ++i)                                       \
+            stg[i] = *reinterpret_cast<const u32x4*>(plane + goff[i]);                        \
+    }
+#define MVS_STORE_A()                                                                         \
+    {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < PPT; ++i)                                       \
+            if (loff[i] >= 0)                                                                 \
+                *reinterpret_cast<u32x4*>(tile + loff[i]) =                                   \
+                    ((inside >> i) & 1u) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};                  \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c < 3) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int koff = (((ks / 3) * HY + ks % 3) * HX) * VS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(abase + koff + i * HX * VS);
+                acc[i] = mfma16<DT>(a, breg[ks], acc[i]);
+            }
+        }
+        if (c < 3) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    const int n = lane & 15, jj = n >> 3, co = n & 7;
+    const float bv = bias[co];
+    const int gz = z0 + zt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = y0 + yt0 + i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gx = x0 + 2 * m + jj;
+            if (gz < D && gy < H && gx < W)
+                St<DT>::store1(y, (((size_t)gz * H + gy) * W + gx) * 8 + co, fmaxf(acc[i][e] + bv, 0.0f));
+        }
+    }
+}
+
+// wfold [27][32][8] -> bp [4][9][64][8] (16-bit): k = (g = kx', j = ci of the chunk), n = (jj, co)
+void pack_conv0p16_weights(const float* wfold, int dt, unsigned short* bp) {
+    for (int c = 0; c < 4; ++c)
+        for (int ks = 0; ks < 9; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = lane >> 4, n = lane & 15;
+                    const int kz = ks / 3, ky = ks % 3, jj = n >> 3, co = n & 7;
+                    const int kx = g - jj, ci = 8 * c + j;
+                    float v = 0.0f;
+                    if (kx >= 0 && kx <= 2) v = wfold[((size_t)(kz * 9 + ky * 3 + kx) * 32 + ci) * 8 + co];
+                    bp[(((size_t)c * 9 + ks) * 64 + lane) * 8 + j] = to_bits16(v, dt);
+                }
+}
+
+// =============================================================================================
+// deconvg16: conv7 / conv9 / conv11 (+ skip)
+// =============================================================================================
+struct Deconv16Tap { int cls, kz, dz, ky, dy, valid; };
+// k-step ks, combo q (= g>>1): 5 k-steps x 2 (z,y)-tap combos, each with dx = g&1
+__host__ __device__ constexpr Deconv16Tap deconv16_tap(int ks, int q) {
+    return ks == 0 ? (q == 0 ? Deconv16Tap{0, 1, 0, 1, 0, 1} : Deconv16Tap{0, 1, 0, 1, 0, 0})
+         : ks == 1 ? (q == 0 ? Deconv16Tap{1, 1, 0, 2, 0, 1} : Deconv16Tap{1, 1, 0, 0, 1, 1})
+         : ks == 2 ? (q == 0 ? Deconv16Tap{2, 2, 0, 1, 0, 1} : Deconv16Tap{2, 0, 1, 1, 0, 1})
+         : ks == 3 ? (q == 0 ? Deconv16Tap{3, 2, 0, 2, 0, 1} : Deconv16Tap{3, 2, 0, 0, 1, 1})
+                   : (q == 0 ? Deconv16Tap{3, 0, 1, 2, 0, 1} : Deconv16Tap{3, 0, 1, 0, 1, 1});
+}
+
+template <int CIN, int COUT, int BZ, int BY, int BX>
+struct DeconvG16 {
+    static constexpr int NTT = 2 * COUT / 16;
+    static constexpr int MG = 4 / NTT;
+    static constexpr int MT = BZ * BY * BX;
+    static constexpr int MPW = MT / MG;
+    static constexpr int NCH = CIN / 8;
+    static constexpr int KS = 5;
+    static constexpr int VS = 8;
+    static constexpr int HZ = BZ + 1, HY = 2 * BY + 1, HX = 8 * BX + 1;
+    static constexpr int HXP = ((HX + 7) / 8 * 8) | 8;
+    static constexpr int TILE_ELEMS = HZ * HY * HXP * VS;
+    static constexpr int NPIECE = HZ * HY * HX;
+    static constexpr int PPT = (NPIECE + 255) / 256;
+    static_assert(NTT == 1 || NTT == 2 || NTT == 4, "COUT must be 8, 16 or 32");
+    static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
+};
+
+template <int DT, int CIN, int COUT, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void deconvg16_mfma_kernel(
+    const void* __restrict__ x, const unsigned short* __restrict__ bp, const float* __restrict__ bias,
+    const void* __restrict__ skip, void* __restrict__ y, int Di, int Hi, int Wi) {
+    using G = DeconvG16<CIN, COUT, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[G::TILE_ELEMS];
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NTT, mg = wave / G::NTT;
+    const int nbx = (Wi + 8 * BX - 1) / (8 * BX), nby = (Hi + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ix0 = bx * 8 * BX, iy0 = by * 2 * BY, iz0 = bz * BZ;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = Vin * 8;
+
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int v = tid + i * 256;
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = v < G::NPIECE && gz < Di && gy < Hi && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = (v < G::NPIECE) ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS : -1;
+    }
+
+    const int r = lane & 15, g = lane >> 4;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = ((tz * G::HY + 2 * ty + ry) * G::HXP + 8 * tx + rx + (g & 1)) * G::VS;
+    }
+    int koff[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        const Deconv16Tap t0 = deconv16_tap(ks, 0), t1 = deconv16_tap(ks, 1);
+        koff[ks] = (g >> 1) ? (t1.dz * G::HY + t1.dy) * G::HXP * G::VS : (t0.dz * G::HY + t0.dy) * G::HXP * G::VS;
+    }
+
+    f32x4 acc[4][G::MPW];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 breg[G::KS];
+    u32x4 stg[G::PPT];
+
+#define MVS_LOAD_B(C)                                                                               \
+    {                                                                                               \
+        const u32x4* bsrc =                                                                         \
+            reinterpret_cast<const u32x4*>(bp) + ((size_t)((C) * G::NTT + nt) * G::KS) * 64 + lane; \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];              \
+    }
+#define MVS_LOAD_A(C)                                                                               \
+    {                                                                                               \
+        const unsigned short* plane = xs + (size_t)(C) * Vin * 8;                                   \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            stg[i] = *reinterpret_cast<const u32x4*>(plane + goff[i]);                              \
+    }
+#define MVS_STORE_A()                                                                               \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            if (loff[i] >= 0)                                                                       \
+                *reinterpret_cast<u32x4*>(tile + loff[i]) =                                         \
+                    ((inside >> i) & 1u) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};                        \
+    }
+
+    MVS_LOAD_B(0)
+    MVS_LOAD_A(0)
+    MVS_STORE_A()
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) MVS_LOAD_A(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int cls = deconv16_tap(ks, 0).cls;
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(tile + abase[i] + koff[ks]);
+                acc[cls][i] = mfma16<DT>(a, breg[ks], acc[cls][i]);
+            }
+        }
+        if (c + 1 < G::NCH) {
+            MVS_LOAD_B(c + 1)
+            __syncthreads();
+            MVS_STORE_A()
+            __syncthreads();
+        }
+    }
+#undef MVS_LOAD_B
+#undef MVS_LOAD_A
+#undef MVS_STORE_A
+
+    const int nn = 16 * nt + (lane & 15);
+    const int px = nn / COUT, co = nn % COUT;
+    const float bv = bias[co];
+    const size_t plane_off = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = iz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = iy0 + 2 * ty + (m >> 3), gx = ix0 + 8 * tx + (m & 7);
+            if (gz < Di && gy < Hi && gx < Wi) {
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
+                    const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
+                    St<DT>::store1(y, o, fmaxf(acc[cls][i][e] + bv, 0.0f) + St<DT>::load1(skip, o));
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int CIN, int COUT, int BZ, int BY, int BX>
+static int run_deconvg16(const void* x, const void* skip, void* y, const unsigned short* bp,
+                         const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "deconvg16_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wi + 8 * BX - 1) / (8 * BX)) * ((Hi + 2 * BY - 1) / (2 * BY)) * ((Di + BZ - 1) / BZ);
+    deconvg16_mfma_kernel<DT, CIN, COUT, BZ, BY, BX><<<nb, 256, 0, s>>>(x, bp, bias, skip, y, Di, Hi, Wi);
+    return check_hip(hipGetLastError(), "deconvg16_mfma launch");
+}
+
+// wfold [27][cin][cout] -> bp [cin/8][2*cout/16][5][64][8] (16-bit)
+void pack_deconvg16_weights(const float* wfold, int cin, int cout, int dt, unsigned short* bp) {
+    const int nch = cin / 8, ntt = 2 * cout / 16;
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < ntt; ++t)
+            for (int ks = 0; ks < 5; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int g = lane >> 4, n = lane & 15, dx = g & 1;
+                        const Deconv16Tap tp = deconv16_tap(ks, g >> 1);
+                        const int ci = 8 * c + j;
+                        const int nn = 16 * t + n, px = nn / cout, co = nn % cout;
+                        const int kx = px == 0 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 2 : 0);
+                        const float v = (!tp.valid || kx < 0)
+                                            ? 0.0f
+                                            : wfold[((size_t)(tp.kz * 9 + tp.ky * 3 + kx) * cin + ci) * cout + co];
+                        bp[((((size_t)c * ntt + t) * 5 + ks) * 64 + lane) * 8 + j] = to_bits16(v, dt);
+                    }
+}
+
+// =============================================================================================
+// dispatch for layers 0..9 in the 16-bit storage modes
+// =============================================================================================
+template <int DT>
+static int launch_layer16_dt(int layer, const void* x, const void* skip, void* y, const unsigned short* bp,
+                             const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
+    if (layer == 0) {
+        using namespace c16;
+        if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+            return fail(MVS_ERR_BAD_SHAPE, "conv0p16_mfma: plane exceeds 31-bit offsets");
+        const int nb = ((Wi + TX - 1) / TX) * ((Hi + TY - 1) / TY) * ((Di + TZ - 1) / TZ);
+        conv0p16_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bp, bias, y, Di, Hi, Wi);
+        return check_hip(hipGetLastError(), "conv0p16_mfma launch");
+    }
+    if (layer <= 6) return launch_convg16_dt<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s);
+    switch (layer) {
+        case 7: return run_deconvg16<DT, 64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 8: return run_deconvg16<DT, 32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 9: return run_deconvg16<DT, 16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "mfma16: layer %d not covered", layer);
+    }
+}
+
+int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, const void* panel,
+                        const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
+    const unsigned short* bp = static_cast<const unsigned short*>(panel);
+    if (dtype == MVS_F16) return launch_layer16_dt<MVS_F16>(layer, x, skip, y, bp, bias, Di, Hi, Wi, s);
+    if (dtype == MVS_BF16) return launch_layer16_dt<MVS_BF16>(layer, x, skip, y, bp, bias, Di, Hi, Wi, s);
+    return fail(MVS_ERR_BAD_DTYPE, "mfma16 kernels need fp16 or bf16 storage (dtype %d)", dtype);
+}
+
+// 16-bit elements of the panel of layer l (0..9)
+size_t mfma16_panel_elems(int layer) {
+    const LayerSpec& S = kLayers[layer];
+    if (layer == 0) return (size_t)4 * 9 * 64 * 8;
+    if (layer <= 6) return (size_t)(S.cin / 8) * (S.cout / 16) * 7 * 64 * 8;
+    return (size_t)(S.cin / 8) * (2 * S.cout / 16) * 5 * 64 * 8;
+}
+
+void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out) {
+    unsigned short* bp = static_cast<unsigned short*>(out);
+    const LayerSpec& S = kLayers[layer];
+    if (layer == 0) pack_conv0p16_weights(wfold, dt, bp);
+    else if (layer <= 6) pack_convg16_weights(wfold, S.cin, S.cout, dt, bp);
+    else pack_deconvg16_weights(wfold, S.cin, S.cout, dt, bp);
+}
+
+}  // namespace mvs

@@ -112,6 +112,9 @@ int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_pa
         pack_convg_weights(blob + L.w_off[l], kLayers[l].cin, kLayers[l].cout, blob + L.gp_off[l]);
     for (int l = 7; l <= 9; ++l)
         pack_deconvg_weights(blob + L.w_off[l], kLayers[l].cin, kLayers[l].cout, blob + L.gp_off[l]);
+    for (int d = 0; d < 2; ++d)
+        for (int l = 0; l < 10; ++l)
+            pack_mfma16_panel(l, blob + L.w_off[l], d == 0 ? MVS_F16 : MVS_BF16, blob + L.h16_off[d][l]);
     return MVS_OK;
 }
 

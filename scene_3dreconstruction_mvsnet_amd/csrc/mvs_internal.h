@@ -42,6 +42,7 @@ struct BlobLayout {
     size_t c0p_off;                // conv0 Toeplitz "pair" panel [4][18][64][4] (conv3d_mfma.hip)
     size_t c0q_off;                // conv0 4x4x1 panel [4][27][2][2][4][4] (conv3d_mfma.hip)
     size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 and deconv panels of 7..9
+    size_t h16_off[2][10];         // 16-bit MFMA panels of layers 0..9 for MVS_F16 ([0]) / MVS_BF16 ([1])
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -67,6 +68,14 @@ inline BlobLayout blob_layout() {
         L.gp_off[l] = off;
         off += (size_t)(kLayers[l].cin / 8) * (2 * kLayers[l].cout / 16) * 9 * 64 * 4;
     }
+    for (int d = 0; d < 2; ++d)
+        for (int l = 0; l < 10; ++l) {
+            const size_t elems = l == 0 ? (size_t)4 * 9 * 64 * 8
+                               : l <= 6 ? (size_t)(kLayers[l].cin / 8) * (kLayers[l].cout / 16) * 7 * 64 * 8
+                                        : (size_t)(kLayers[l].cin / 8) * (2 * kLayers[l].cout / 16) * 5 * 64 * 8;
+            L.h16_off[d][l] = off;
+            off += (elems / 2 + 63) & ~(size_t)63;
+        }
     L.total_floats = off;
     return L;
 }
@@ -133,6 +142,9 @@ void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp);
+int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, const void* panel,
+                        const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
+void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out);
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s);
 int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,

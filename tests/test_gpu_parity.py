@@ -277,6 +277,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE": "1"},           # fused warp+variance+conv0 kernel inside mvs_depth_infer
+    {"MVS_PROB_GATHER": "1"},    # prob conv with global gathers instead of the LDS tile
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each
@@ -287,6 +288,32 @@ def test_optin_kernel_variants(env):
     here = os.path.dirname(os.path.abspath(__file__))
     child_env = dict(os.environ, **env)
     r = subprocess.run([sys.executable, os.path.join(here, "variant_check.py")], env=child_env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
+def test_16bit_storage_fp32_arithmetic_variant(storage):
+    """MVS_MFMA16=0: fp32 MFMA on the narrowed operands, against the oracle that rounds storage only."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_fixture, load_weights, rel_l1\n"
+        "from oracle import oracle as orc\n"
+        "from scene_3dreconstruction_mvsnet_amd import _lib\n"
+        "fx = load_fixture('small'); sd = orc.costreg_state(load_weights()); st = %r\n"
+        "f, p, d = fx['features'][0], fx['proj_matrices'][0], fx['depth_values'][0]\n"
+        "dev = 'cuda:0'; cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)\n"
+        "N, C, h, w = f.shape; dt = _lib.dtype_code(st)\n"
+        "ws = _lib.alloc_workspace(N, C, d.shape[0], h, w, dev, dt)\n"
+        "depth = torch.empty((h, w), device=dev); conf = torch.empty_like(depth)\n"
+        "_lib.depth_infer(cu(f), cu(p), cu(d), _lib.pack_weights(sd).to(dev), ws, depth, conf, dtype=dt)\n"
+        "want, _ = orc.depth_infer(f, p, d, sd, storage=st, arith16=False)\n"
+        "r = rel_l1(depth.cpu().numpy(), want); print(r); sys.exit(0 if r < (2e-4 if st == 'f16' else 1e-3) else 1)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), storage)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVS_MFMA16="0"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -387,29 +414,33 @@ def test_16bit_layers_match_matched_oracle(storage):
     sd = synthetic.random_costreg_state(seed=3)
     blob = blob_for(sd)
     rng = np.random.default_rng(1)
-    for layer in (0, 2, 5, 8, 10):
+    q = lambda t: orc.round_storage(t, storage)  # noqa: E731
+    for layer in range(11):
         ci, co = _lib._LAYER_CH[layer]
-        x = orc.round_storage(rng.standard_normal((ci, 8, 8, 16)).astype(np.float32), storage)
+        x = q(rng.standard_normal((ci, 8, 8, 16)).astype(np.float32))
         key = _lib.CONV_WEIGHT_KEYS[layer]
         xt = _lib.to_c8(cu(x)).to(tdt)
-        if layer == 10:
+        if layer == 10:  # prob: fp32 weights, VALU
             want = orc.conv3d(x, sd[key], bias=sd["prob.bias"], bn=None, relu=False)[0]
             got = _lib.conv_layer(10, xt, None, blob, dtype=code).cpu().numpy()
             np.testing.assert_allclose(got, want, rtol=0, atol=3e-4 * max(np.abs(want).max(), 1.0))
             continue
+        # 16-bit MFMA mode: BN-folded weights rounded to the storage dtype, fp32 accumulation
         if layer >= 7:
-            skip = orc.round_storage(rng.standard_normal((co, 16, 16, 32)).astype(np.float32), storage)
-            want = skip + orc.deconv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]))
+            w, sh = orc._fold(sd, key, _lib.BN_PREFIXES[layer], transposed=True)
+            wt = np.ascontiguousarray(q(w).transpose(1, 0, 2, 3, 4))
+            skip = q(rng.standard_normal((co, 16, 16, 32)).astype(np.float32))
+            want = skip + np.maximum(orc.deconv3d(x, wt, bn=None, relu=False) + sh[:, None, None, None], 0.0)
             y = _lib.conv_layer(layer, xt, _lib.to_c8(cu(skip)).to(tdt), blob, dtype=code)
         else:
+            w, sh = orc._fold(sd, key, _lib.BN_PREFIXES[layer])
             stride = 2 if layer in (1, 3, 5) else 1
-            want = orc.conv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]), stride=stride)
+            want = orc.conv3d(x, q(w), bias=sh, bn=None, stride=stride, relu=True)
             y = _lib.conv_layer(layer, xt, None, blob, dtype=code)
         assert y.dtype == tdt
         got = _lib.from_c8(y.float()).cpu().numpy()
         # one storage ulp of slack on top of fp32 summation noise
-        np.testing.assert_allclose(got, orc.round_storage(want, storage), rtol=2 * eps,
-                                   atol=3e-4 * max(np.abs(want).max(), 1.0))
+        np.testing.assert_allclose(got, q(want), rtol=2 * eps, atol=3e-4 * max(np.abs(want).max(), 1.0))
 
 
 # ------------------------------------------------------------------------------ other BASELINE configs

@@ -119,6 +119,26 @@ def test_pack_weights_folds_bn_and_relayouts():
     for l in range(7, 10):  # deconv panels [cin/8][2*cout/16][9][64][4]
         ci, co = layer_ch[l]
         off += (ci // 8) * (2 * co // 16) * 9 * 64 * 4
+    # 16-bit MFMA panels (fp16 then bf16), layers 0..9; spot-check the conv2 panel's rounding
+    for d, npdt in enumerate(("f16", "bf16")):
+        for l in range(10):
+            ci, co = layer_ch[l]
+            elems = 4 * 9 * 64 * 8 if l == 0 else (ci // 8) * (co // 16) * 7 * 64 * 8 if l <= 6 \
+                else (ci // 8) * (2 * co // 16) * 5 * 64 * 8
+            if l == 2:
+                panel = blob[off:off + elems // 2].view(np.uint16).reshape(ci // 8, co // 16, 7, 64, 8)
+                wl = blob[woffs[l]:woffs[l] + 27 * ci * co].reshape(27, ci, co)
+                for c, t, ks, lane, j in [(0, 0, 0, 0, 0), (1, 0, 6, 63, 7), (1, 0, 3, 37, 2)]:
+                    g, n = lane >> 4, lane & 15
+                    tap = 4 * ks + g
+                    want = wl[tap, 8 * c + j, 16 * t + n] if tap < 27 else np.float32(0)
+                    if npdt == "f16":
+                        bits = np.array([want], np.float32).astype(np.float16).view(np.uint16)[0]
+                    else:
+                        u = int(np.array([want], np.float32).view(np.uint32)[0])
+                        bits = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
+                    assert panel[c, t, ks, lane, j] == bits
+            off += (elems // 2 + 63) // 64 * 64
     assert off * 4 == _lib.query_weights_blob()
 
 
