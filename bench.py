@@ -299,7 +299,9 @@ def main():
             "value": round(maps_per_s, 3), "unit": "depth maps/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if storage == "f32" else f"f32 arithmetic, {storage} storage",
+            "dtype": "f32" if storage == "f32" else (
+                f"{storage} storage, f32 MFMA arithmetic" if os.environ.get("MVS_MFMA16") == "0"
+                else f"{storage} storage and MFMA operands, f32 accumulation"),
             "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N} views, {cfg['H']}x{cfg['W']} image -> "
                                    f"{h}x{w} features, D={D}, C=32, {storage} volumes; path-only (features "

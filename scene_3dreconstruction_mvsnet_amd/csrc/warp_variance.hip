@@ -121,7 +121,7 @@ int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
 constexpr int kWarpDepthSlab = 8;
 constexpr int kWarpPixPerBlock = 128;
 
-template <int DT>
+template <int DT, bool DEPTH_FASTEST>
 __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restrict__ feats_p,
                                                             const float* __restrict__ rt,
                                                             const float* __restrict__ dv,
@@ -129,10 +129,17 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
                                                             int h, int w) {
     const int half = threadIdx.x & 1;
     const int hw = h * w;
-    const int p = blockIdx.x * kWarpPixPerBlock + (threadIdx.x >> 1);
+    // Block order.  DEPTH_FASTEST (feature maps larger than the L2s, e.g. 1600x1184 inputs): x =
+    // depth slab, y = pixel block, so blocks resident together work on the same pixels at
+    // neighbouring depths and share their source footprints in L2 (3.4 -> 2.0 ms at cfg3).
+    // Otherwise x = pixel block: the features stay L2-resident anyway and the volume is written
+    // plane by plane.
+    const int pblk = DEPTH_FASTEST ? blockIdx.y : blockIdx.x;
+    const int dblk = DEPTH_FASTEST ? blockIdx.x : blockIdx.y;
+    const int p = pblk * kWarpPixPerBlock + (threadIdx.x >> 1);
     if (p >= hw) return;
     const int y = p / w, x = p - y * w;
-    const int d0 = blockIdx.y * kWarpDepthSlab;
+    const int d0 = dblk * kWarpDepthSlab;
     const int d1 = min(d0 + kWarpDepthSlab, D);
     const size_t plane_stride = (size_t)N * hw * 8;  // floats between channel planes
     const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
@@ -206,11 +213,24 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
         return e && e[0] == '1';
     }();
     if (use_lds && N <= 64 && dtype == MVS_F32) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
-    dim3 grid((h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock, (D + kWarpDepthSlab - 1) / kWarpDepthSlab);
-    if (dtype == MVS_F32) warp_variance_kernel<MVS_F32><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
-    else if (dtype == MVS_F16) warp_variance_kernel<MVS_F16><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
-    else if (dtype == MVS_BF16) warp_variance_kernel<MVS_BF16><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w);
-    else return fail(MVS_ERR_BAD_DTYPE, "warp_variance: unknown dtype %d", dtype);
+    const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
+    const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
+    float* v = static_cast<float*>(var);
+    // all views' features (N x 32 channels x fp32) against the 32 MB of aggregate L2
+    const bool depth_fastest = (size_t)N * h * w * 128 > ((size_t)24 << 20);
+    if (depth_fastest) {
+        dim3 grid(nd, np);
+        if (dtype == MVS_F32) warp_variance_kernel<MVS_F32, true><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else if (dtype == MVS_F16) warp_variance_kernel<MVS_F16, true><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else if (dtype == MVS_BF16) warp_variance_kernel<MVS_BF16, true><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else return fail(MVS_ERR_BAD_DTYPE, "warp_variance: unknown dtype %d", dtype);
+    } else {
+        dim3 grid(np, nd);
+        if (dtype == MVS_F32) warp_variance_kernel<MVS_F32, false><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else if (dtype == MVS_F16) warp_variance_kernel<MVS_F16, false><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else if (dtype == MVS_BF16) warp_variance_kernel<MVS_BF16, false><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);
+        else return fail(MVS_ERR_BAD_DTYPE, "warp_variance: unknown dtype %d", dtype);
+    }
     return check_hip(hipGetLastError(), "warp_variance launch");
 }
 
