@@ -118,7 +118,10 @@ int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
 // L1/L2 (the epipolar shift per depth step is a fraction of a pixel).
 //   feats_p [4][N][h][w][8], rt [(N-1)][12], dv [D] -> var [4][D][h][w][8]
 // ---------------------------------------------------------------------------------------------
-constexpr int kWarpDepthSlab = 8;
+#ifndef MVS_WARP_SLAB
+#define MVS_WARP_SLAB 8
+#endif
+constexpr int kWarpDepthSlab = MVS_WARP_SLAB;
 constexpr int kWarpPixPerBlock = 128;
 
 template <int DT, bool DEPTH_FASTEST>
