@@ -17,6 +17,10 @@
 #include "mvs_internal.h"
 #include "storage.h"
 
+#ifndef MVS_ABLATE
+#define MVS_ABLATE 0
+#endif
+
 namespace mvs {
 
 template <int CIN, int COUT, int CPT, int STRIDE, bool DECONV, bool RELU, bool SKIP>
@@ -287,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ y, int D, int H, int W) {
     using namespace pl;
-    __shared__ __attribute__((aligned(16))) float tile[HZ * HY * HX * 8];
+    __shared__ __attribute__((aligned(16))) float tile[HZ * HY * HX * 8 + 27 * 8];
+    float* wl = tile + HZ * HY * HX * 8;  // the 27 x 8 weights
     const int tid = threadIdx.x;
     const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
     int b = blockIdx.x;
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
     const int by = b % nby;
     const int bz = b / nby;
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    if (tid < 27 * 8) wl[tid] = wgt[tid];
 
     float4 stg[PPT];
 #pragma unroll
@@ -306,8 +312,13 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t off = ok ? (((size_t)gz * H + gy) * W + gx) * 8 + half * 4 : 0;
+#if MVS_ABLATE == 6  // diagnostic: no staging loads
+        (void)off;
+        stg[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#else
         const f32x4 val = St<DT>::load4(x, off);
         stg[i] = ok ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -323,26 +334,39 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
     const float bv = bias[0];
 #pragma unroll
     for (int j = 0; j < TZ; ++j) acc[j] = bv;
-#pragma unroll
-    for (int c = 0; c < HZ; ++c)
+    // weights come from LDS as broadcast reads: scalar (SMEM) loads would share lgkmcnt with the
+    // tile reads and return out of order, forcing a full drain in front of every use
+#if MVS_ABLATE == 5  // diagnostic: one tap only
+#define MVS_PROB_KH 1
+#else
+#define MVS_PROB_KH 3
+#endif
 #pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh)  // not unrolled: keeps the live LDS reads (and VGPRs) bounded
+    for (int kh = 0; kh < MVS_PROB_KH; ++kh)
+#pragma unroll 1
+        for (int kw = 0; kw < MVS_PROB_KH; ++kw) {
+            const int hx = tx + kw;
+            const int sw = ((hx >> 3) & 1) * 4;
+            const float* vp = tile + ((ty + kh) * HX + hx) * 8;
+            float4 a[HZ], bq[HZ];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int hx = tx + kw;
-                const float* vp = tile + ((c * HY + ty + kh) * HX + hx) * 8;
-                const int sw = ((hx >> 3) & 1) * 4;
-                const float4 a = *reinterpret_cast<const float4*>(vp + sw);        // channels 0..3
-                const float4 bq = *reinterpret_cast<const float4*>(vp + (4 - sw));  // channels 4..7
+            for (int c = 0; c < HZ; ++c) {
+                a[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + sw);         // channels 0..3
+                bq[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + (4 - sw));  // channels 4..7
+            }
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float* wv = wl + ((kd * 3 + kh) * 3 + kw) * 8;
+                const float4 w0 = *reinterpret_cast<const float4*>(wv);
+                const float4 w1 = *reinterpret_cast<const float4*>(wv + 4);
 #pragma unroll
                 for (int j = 0; j < TZ; ++j) {
-                    const int kd = c - j;
-                    if (kd < 0 || kd > 2) continue;
-                    const float* wv = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * 8;
-                    acc[j] = fmaf(a.x, wv[0], fmaf(a.y, wv[1], fmaf(a.z, wv[2], fmaf(a.w, wv[3], acc[j]))));
-                    acc[j] = fmaf(bq.x, wv[4], fmaf(bq.y, wv[5], fmaf(bq.z, wv[6], fmaf(bq.w, wv[7], acc[j]))));
+                    const int c = j + kd;  // input plane of output j through tap kd
+                    acc[j] = fmaf(a[c].x, w0.x, fmaf(a[c].y, w0.y, fmaf(a[c].z, w0.z, fmaf(a[c].w, w0.w, acc[j]))));
+                    acc[j] = fmaf(bq[c].x, w1.x, fmaf(bq[c].y, w1.y, fmaf(bq[c].z, w1.z, fmaf(bq[c].w, w1.w, acc[j]))));
                 }
             }
+        }
     const int gy = y0 + ty, gx = x0 + tx;
     if (gy < H && gx < W) {
 #pragma unroll

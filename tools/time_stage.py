@@ -21,7 +21,7 @@ blob = _lib.pack_weights(synthetic.random_costreg_state(0)).to(dev)
 ws = _lib.alloc_workspace(N, 32, D, h, w, dev)
 rt = _lib.relative_proj(proj)
 var = _lib.warp_variance(feats, rt, dv, ws)
-layer = {"conv0": 0, "conv1": 1, "conv2": 2}.get(what)
+layer = {"conv0": 0, "conv1": 1, "conv2": 2, "prob": 10}.get(what)
 
 
 def run():
@@ -32,7 +32,9 @@ def run():
 
 
 x_in = None
-if layer in (1, 2):
+if layer == 10:
+    x_in = torch.randn((1, D, h, w, 8), device=dev)
+elif layer in (1, 2):
     x_in = _lib.conv_layer(0, var, None, blob)
     if layer == 2:
         x_in = _lib.conv_layer(1, x_in, None, blob)
