@@ -138,7 +138,16 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
         return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
-    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, s)) return st;
+    // 16-bit modes: the feature copy is narrowed too (half the gather bytes) unless MVS_FEAT16=0
+    static const bool feat16 = [] {
+        const char* e = getenv("MVS_FEAT16");
+        return !(e && e[0] == '0');
+    }();
+    if (feat16 && dtype != MVS_F32) {
+        if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, dtype, s)) return st;
+        return launch_warp_variance16(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
+    }
+    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
     return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
 }
 
@@ -199,7 +208,7 @@ int mvs_warp_conv0(const float* feats, const float* rt, const float* depth_value
         return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
-    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, s)) return st;
+    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
     const BlobLayout L = blob_layout();
     const float* blob = static_cast<const float*>(weights_blob);
     return launch_warp_conv0_fused(feats_t, rt, depth_values, blob + L.c0p_off, blob + L.b_off[0],

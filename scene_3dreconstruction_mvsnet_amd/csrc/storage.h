@@ -73,6 +73,36 @@ struct St<MVS_BF16> {
     }
 };
 
+// 8 consecutive 16-bit elements (one voxel of one C8 plane) <-> 8 floats
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+template <int DT>
+__device__ __forceinline__ void load8_16(const void* base, size_t idx, float (&o)[8]) {
+    if (DT == MVS_F16) {
+        const f16x8s h = *reinterpret_cast<const f16x8s*>(static_cast<const _Float16*>(base) + idx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+    } else {
+        const bf16x8s h = *reinterpret_cast<const bf16x8s*>(static_cast<const __bf16*>(base) + idx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store8_16(void* base, size_t idx, const float (&v)[8]) {
+    if (DT == MVS_F16) {
+        f16x8s h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i];
+        *reinterpret_cast<f16x8s*>(static_cast<_Float16*>(base) + idx) = h;
+    } else {
+        bf16x8s h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (__bf16)v[i];
+        *reinterpret_cast<bf16x8s*>(static_cast<__bf16*>(base) + idx) = h;
+    }
+}
+
 // dispatch a launcher template over the runtime dtype
 #define MVS_DISPATCH_DTYPE(dtype, CALL)                                   \
     switch (dtype) {                                                      \

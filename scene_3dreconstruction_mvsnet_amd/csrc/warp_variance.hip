@@ -29,8 +29,9 @@ namespace mvs {
 // [N][C=32][h][w] -> C8-planar [4][N][h][w][8]; one block transposes 32 channels x 64 pixels
 // through LDS.
 // ---------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ in,
-                                                         float* __restrict__ out, int N, int hw) {
+                                                         void* __restrict__ out, int N, int hw) {
     __shared__ float tile[32][65];
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * 64;
@@ -48,15 +49,18 @@ __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int q = pass * 32 + pp, p = p0 + q;
-            if (p < hw) out[(((size_t)pl * N + n) * hw + p) * 8 + c8] = tile[pl * 8 + c8][q];
+            if (p < hw) St<DT>::store1(out, (((size_t)pl * N + n) * hw + p) * 8 + c8, tile[pl * 8 + c8][q]);
         }
 }
 
-int launch_nchw_to_c8(const float* in, float* out, int N, int C, int h, int w, hipStream_t s) {
+int launch_nchw_to_c8(const float* in, void* out, int N, int C, int h, int w, int dtype, hipStream_t s) {
     (void)C;
     const int hw = h * w;
     dim3 grid((hw + 63) / 64, N);
-    nchw_to_c8_kernel<<<grid, 256, 0, s>>>(in, out, N, hw);
+    if (dtype == MVS_F32) nchw_to_c8_kernel<MVS_F32><<<grid, 256, 0, s>>>(in, out, N, hw);
+    else if (dtype == MVS_F16) nchw_to_c8_kernel<MVS_F16><<<grid, 256, 0, s>>>(in, out, N, hw);
+    else if (dtype == MVS_BF16) nchw_to_c8_kernel<MVS_BF16><<<grid, 256, 0, s>>>(in, out, N, hw);
+    else return fail(MVS_ERR_BAD_DTYPE, "nchw_to_c8: unknown dtype %d", dtype);
     return check_hip(hipGetLastError(), "nchw_to_c8 launch");
 }
 
@@ -204,6 +208,96 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(const float* __restr
                            (f32x4){o.x, o.y, o.z, o.w});
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit modes: the C8-planar feature copy is stored in the storage dtype too, so one 16-byte
+// load is a whole 8-channel tap -- half the bytes through the vector-L1 path that bounds the fp32
+// kernel.  Thread = (pixel, plane pair): 2 planes x 8 channels; arithmetic stays fp32.
+//   feats16 [4][N][h][w][8] (DT), rt, dv -> var [4][D][h][w][8] (DT)
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool DEPTH_FASTEST>
+__global__ __launch_bounds__(256) void warp_variance16_kernel(const void* __restrict__ feats16,
+                                                              const float* __restrict__ rt,
+                                                              const float* __restrict__ dv,
+                                                              void* __restrict__ var, int N, int D,
+                                                              int h, int w) {
+    const int hp = threadIdx.x & 1;  // planes 2hp, 2hp+1
+    const int hw = h * w;
+    const int pblk = DEPTH_FASTEST ? blockIdx.y : blockIdx.x;
+    const int dblk = DEPTH_FASTEST ? blockIdx.x : blockIdx.y;
+    const int p = pblk * kWarpPixPerBlock + (threadIdx.x >> 1);
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const int d0 = dblk * kWarpDepthSlab;
+    const int d1 = min(d0 + kWarpDepthSlab, D);
+    const size_t plane_stride = (size_t)N * hw * 8;  // elements between channel planes
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)x, fy = (float)y;
+    const float inv_n = 1.0f / (float)N;
+    const size_t V0 = (size_t)D * hw;
+    float ref[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) load8_16<DT>(feats16, (size_t)(2 * hp + q) * plane_stride + (size_t)p * 8, ref[q]);
+    for (int d = d0; d < d1; ++d) {
+        const float depth = dv[d];
+        float S[2][8], Q[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { S[q][c] = ref[q][c]; Q[q][c] = ref[q][c] * ref[q][c]; }
+        for (int v = 1; v < N; ++v) {
+            const float* r = rt + (size_t)(v - 1) * 12;
+            const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+            const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+            const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+            const Samp t = make_samp(qx, qy, qz, r[9], r[10], r[11], depth, sx, sy, h, w, 0, 0, w, h);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const size_t base = (size_t)(2 * hp + q) * plane_stride + (size_t)v * hw * 8;
+                float a[8], b[8], c[8], e[8];
+                load8_16<DT>(feats16, base + (size_t)t.o00 * 8, a);
+                load8_16<DT>(feats16, base + (size_t)t.o01 * 8, b);
+                load8_16<DT>(feats16, base + (size_t)t.o10 * 8, c);
+                load8_16<DT>(feats16, base + (size_t)t.o11 * 8, e);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float wv = fmaf(a[k], t.w00, fmaf(b[k], t.w01, fmaf(c[k], t.w10, e[k] * t.w11)));
+                    S[q][k] += wv;
+                    Q[q][k] = fmaf(wv, wv, Q[q][k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float m = S[q][k] * inv_n;
+                o[k] = fmaf(-m, m, Q[q][k] * inv_n);  // var = Q/N - (S/N)^2   (models/mvsnet.py:177)
+            }
+            store8_16<DT>(var, ((size_t)(2 * hp + q) * V0 + (size_t)d * hw + p) * 8, o);
+        }
+    }
+}
+
+int launch_warp_variance16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
+                           int h, int w, int dtype, hipStream_t s) {
+    if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
+    const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
+    const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
+    const bool depth_fastest = (size_t)N * h * w * 64 > ((size_t)24 << 20);
+    const dim3 grid = depth_fastest ? dim3(nd, np) : dim3(np, nd);
+    if (dtype == MVS_F16) {
+        if (depth_fastest) warp_variance16_kernel<MVS_F16, true><<<grid, 256, 0, s>>>(feats16, rt, dv, var, N, D, h, w);
+        else warp_variance16_kernel<MVS_F16, false><<<grid, 256, 0, s>>>(feats16, rt, dv, var, N, D, h, w);
+    } else if (dtype == MVS_BF16) {
+        if (depth_fastest) warp_variance16_kernel<MVS_BF16, true><<<grid, 256, 0, s>>>(feats16, rt, dv, var, N, D, h, w);
+        else warp_variance16_kernel<MVS_BF16, false><<<grid, 256, 0, s>>>(feats16, rt, dv, var, N, D, h, w);
+    } else {
+        return fail(MVS_ERR_BAD_DTYPE, "warp_variance16 needs fp16 or bf16 (dtype %d)", dtype);
+    }
+    return check_hip(hipGetLastError(), "warp_variance16 launch");
 }
 
 int launch_warp_variance(const float* feats_p, const float* rt, const float* dv, void* var, int N,

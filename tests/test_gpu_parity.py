@@ -407,7 +407,8 @@ def test_16bit_layers_match_matched_oracle(storage):
     ws = _lib.alloc_workspace(feats.shape[0], 32, dv.shape[0], feats.shape[2], feats.shape[3], DEV, code)
     var = _lib.warp_variance(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), ws, dtype=code)
     assert var.dtype == tdt
-    want = orc.round_storage(fx["variance"][0], storage)
+    # 16-bit modes gather from a 16-bit copy of the features (fp32 interpolation / variance)
+    want = orc.round_storage(orc.variance_volume(orc.round_storage(feats, storage), proj, dv), storage)
     eps = 2.0 ** (-10 if storage == "f16" else -7)
     got = _lib.from_c8(var.float()).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=eps, atol=5e-4)
