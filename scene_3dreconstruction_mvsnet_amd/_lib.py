@@ -213,6 +213,8 @@ def warp_conv0(feats, rt, depth_values, blob, workspace, dtype=MVS_F32):
 
 def costreg_forward(var, blob, workspace, dtype=MVS_F32):
     """var [4,D,h,w,8] (C8-planar) -> cost logits [D,h,w] fp32."""
+    if var.dtype != TORCH_DTYPES[dtype] or not var.is_cuda or not var.is_contiguous():
+        raise RuntimeError(f"variance volume must be a contiguous CUDA tensor of {TORCH_DTYPES[dtype]}")
     _, D, h, w, _ = var.shape
     cost = torch.empty((D, h, w), dtype=torch.float32, device=var.device)
     check(load().mvs_costreg_forward(var.data_ptr(), blob.data_ptr(), cost.data_ptr(),
@@ -227,6 +229,10 @@ def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
     planes, Di, Hi, Wi, c8 = x.shape
     if planes * c8 != ci or c8 != 8:
         raise RuntimeError(f"layer {layer}: input has {planes}x{c8} channels, expected {ci}")
+    if x.dtype != TORCH_DTYPES[dtype] or (skip is not None and skip.dtype != TORCH_DTYPES[dtype]):
+        raise RuntimeError(f"layer {layer}: tensors are {x.dtype}, storage dtype says {TORCH_DTYPES[dtype]}")
+    if not x.is_cuda or not x.is_contiguous() or (skip is not None and not skip.is_contiguous()):
+        raise RuntimeError(f"layer {layer}: needs contiguous CUDA(ROCm) tensors")
     if 7 <= layer <= 9:
         odims = (2 * Di, 2 * Hi, 2 * Wi)
     elif layer in (1, 3, 5):
