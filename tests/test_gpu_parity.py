@@ -494,3 +494,24 @@ def test_save_depth_sharded_writes_reference_file_tree(tmp_path):
         np.testing.assert_array_equal(d, out["depth"][0].cpu().numpy())
         np.testing.assert_array_equal(c, out["photometric_confidence"][0].cpu().numpy())
         assert (tmp_path / "scan9" / "cams" / f"{i:08d}_cam.txt").read_text().startswith("extrinsic\n1.0 0.0 ")
+
+
+# ------------------------------------------------------------------------------ randomized shapes
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_and_rigs_match_oracle(seed):
+    """Seeded random problems: ragged tile edges in every axis, 1..9 views, rotated / widely spaced
+    rigs (large out-of-image fractions), different depth ranges -- whole path vs the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(1, 10))
+    h, w, D = (int(8 * rng.integers(1, 6)), int(8 * rng.integers(1, 9)), int(8 * rng.integers(1, 5)))
+    baseline = (float(rng.uniform(-120, 120)), float(rng.uniform(-40, 40)), float(rng.uniform(-5, 5)))
+    feats = synthetic.random_features(N, 32, h, w, seed=seed)
+    proj = synthetic.cameras(N, h, w, baseline=baseline, yaw_deg=float(rng.uniform(-3, 3)))
+    dv = synthetic.depth_values(D, dmin=float(rng.uniform(300, 900)), interval=float(rng.uniform(1.0, 6.0)))
+    sd = synthetic.random_costreg_state(seed=seed)
+    depth, conf = hip_depth_infer(feats, proj, dv, sd)
+    var = orc.variance_volume(feats, proj, dv)
+    cost = orc.costreg_forward(var, sd)
+    depth_o, conf_o, idx_o, prob_o = orc.softargmin_conf(cost, dv, want_prob=True)
+    assert rel_l1(depth, depth_o) < 1e-5, (N, h, w, D)
+    assert_conf_close(conf, conf_o, idx_o, prob=prob_o, atol=1e-3)
