@@ -1,0 +1,122 @@
+"""Eval-time dataset with the semantics of the reference's datasets/dataloader_eval.py
+(SURVEY.md §8 f2): it defines what `MVSNet.forward` is fed during `save_depth` (eval.py:292-305).
+
+Written from the reference's behaviour, not its code:
+  * pair file (dataloader_eval.py:41-49): first line = number of viewpoints; then per viewpoint a
+    line with the reference view id and a line `n id0 score0 id1 score1 ...` (source ids are the
+    odd-position tokens); the same pair file is applied to every scan of the list file
+  * cam file (dataloader_eval.py:54-71): line 0 `extrinsic`, lines 1-4 a 4x4 matrix, line 6
+    `intrinsic`, lines 7-9 a 3x3 matrix, line 11 `depth_min depth_interval ...`; the interval is
+    multiplied by `interval_scale`
+  * image (datasets/data_io.py:76-154): shrink with PIL bilinear by the larger of the two target
+    ratios (never enlarge), centre-crop to the target (or to a multiple of 32 below it), intrinsics
+    rows 0-1 scaled and principal point shifted accordingly, pixels / 255
+  * sample (dataloader_eval.py:101-176): reference view + first nviews-1 sources; intrinsics rows
+    0-1 divided by 4 (feature scale); proj = [[K @ E[:3,:4]], [E[3]]]; depth_values =
+    arange(depth_min, interval*(D-0.5)+depth_min, interval) as float32 from the REFERENCE view's
+    cam file; DTU image files are numbered from 1 (`vid + 1`)
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+from PIL import Image
+
+
+def parse_pair_file(path: str):
+    """-> [(ref_view, [src_views...]), ...]"""
+    with open(path) as f:
+        tokens = f.read().split("\n")
+    n = int(tokens[0])
+    out = []
+    for i in range(n):
+        ref = int(tokens[1 + 2 * i].strip())
+        src = [int(t) for t in tokens[2 + 2 * i].split()[1::2]]
+        out.append((ref, src))
+    return out
+
+
+def parse_cam_file(path: str, interval_scale: float = 1.0):
+    """-> (intrinsics 3x3 f32, extrinsics 4x4 f32, depth_min, depth_interval * interval_scale)"""
+    with open(path) as f:
+        lines = [ln.rstrip() for ln in f.readlines()]
+    extr = np.array(" ".join(lines[1:5]).split(), dtype=np.float32).reshape(4, 4)
+    intr = np.array(" ".join(lines[7:10]).split(), dtype=np.float32).reshape(3, 3)
+    fields = lines[11].split()
+    return intr, extr, float(fields[0]), float(fields[1]) * interval_scale
+
+
+def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512, 640), base: int = 32):
+    """-> (float32 HxWx3 in [0,1], adjusted intrinsics).  `intrinsics` is modified in place too,
+    as the reference does."""
+    img = Image.open(path)
+    w_src, h_src = img.size
+    h_t, w_t = img_res
+    sh, sw = float(h_t) / h_src, float(w_t) / w_src
+    if sh > 1 or sw > 1:
+        raise ValueError("target resolution must not exceed the image resolution")
+    scale = max(sh, sw)
+    img = img.resize(size=(int(w_src * scale), int(h_src * scale)), resample=Image.BILINEAR)
+    w_r, h_r = img.size
+    intrinsics[:2, :] *= scale
+    final_h = h_t if h_r > h_t else int(math.floor(h_t / base) * base)
+    final_w = w_t if w_r > w_t else int(math.floor(w_t / base) * base)
+    top = int(math.floor((h_r - final_h) / 2))
+    left = int(math.floor((w_r - final_w) / 2))
+    img = img.crop((left, top, left + final_w, top + final_h))
+    intrinsics[0, -1] -= left
+    intrinsics[1, -1] -= top
+    arr = np.array(img, dtype=np.float32) / 255.0
+    if arr.ndim == 2:
+        arr = np.dstack((arr, arr, arr))
+    return arr, intrinsics
+
+
+class EvalDataset:
+    """Same constructor keywords and item dict as the reference's eval MVSDataset."""
+
+    def __init__(self, datapath, listfile, mode="test", nviews=5, ndepths=192, interval_scale=1.06,
+                 pairfile="pair.txt", cam_subfolder="Cameras", img_subfolder="Rectified/{}/rect_{:0>3}_3_r5000.png",
+                 img_res=(512, 640), dataset_name="dtu"):
+        assert mode == "test"
+        self.datapath, self.nviews, self.ndepths = datapath, nviews, ndepths
+        self.interval_scale, self.cam_subfolder, self.img_subfolder = interval_scale, cam_subfolder, img_subfolder
+        self.img_res, self.dataset_name = img_res, dataset_name
+        with open(listfile) as f:
+            scans = [ln.rstrip() for ln in f.readlines()]
+        pair_path = os.path.join(datapath, "../..", pairfile) if dataset_name == "bin" \
+            else os.path.join(datapath, pairfile)
+        pairs = parse_pair_file(pair_path)
+        self.metas = [(scan, ref, src) for scan in scans for ref, src in pairs]
+
+    def __len__(self):
+        return len(self.metas)
+
+    def __getitem__(self, idx):
+        scan, ref_view, src_views = self.metas[idx]
+        view_ids = [ref_view] + src_views[:self.nviews - 1]
+        imgs, projs, intr_list, extr_list = [], [], [], []
+        depth_values = None
+        for i, vid in enumerate(view_ids):
+            img_vid = vid + 1 if self.dataset_name in ("dtu",) else vid
+            img_path = os.path.join(self.datapath, self.img_subfolder.format(scan, img_vid))
+            cam_path = os.path.join(self.datapath, self.cam_subfolder, "{:0>8}_cam.txt".format(vid))
+            intr, extr, dmin, dint = parse_cam_file(cam_path, self.interval_scale)
+            img, intr = load_image_rescaled_cropped(img_path, intr, img_res=self.img_res)
+            imgs.append(img)
+            intr[:2, :] /= 4.0  # feature scale (the network downsamples by 4)
+            intr_list.append(intr)
+            extr_list.append(extr)
+            proj = extr.copy()
+            proj[:3, :4] = np.matmul(intr, proj[:3, :4])
+            projs.append(proj)
+            if i == 0:
+                depth_values = np.arange(dmin, dint * (self.ndepths - 0.5) + dmin, dint, dtype=np.float32)
+        return {"imgs": np.stack(imgs).transpose([0, 3, 1, 2]),
+                "proj_matrices": np.stack(projs),
+                "intrinsics": intr_list,
+                "extrinsics": extr_list,
+                "depth_values": depth_values,
+                "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
