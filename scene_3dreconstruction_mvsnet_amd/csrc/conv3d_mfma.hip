@@ -1,25 +1,32 @@
 // conv3d_mfma.hip -- fp32-MFMA implicit-GEMM 3x3x3 convolutions for gfx950 (MI355X).
 //
-// conv0 of CostRegNet (32 -> 8 channels at full resolution; reference models/mvsnet.py:36,65 with
-// the ConvBnReLU3D block of models/module.py:26-33) is 68 % of the path's FLOPs.  It runs on
-// v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).
+// Every convolution of CostRegNet (reference models/mvsnet.py:35-73, ConvBnReLU3D of
+// models/module.py:26-33) except the 8 -> 1 `prob` layer runs here on exact-fp32 MFMA
+// (64 FLOP/clk/SIMD, bit-equal to an fmaf chain).  Kernels in this file:
+//   conv0_4x4_mfma_kernel    conv0 (32 -> 8, 68 % of the path's FLOPs) on v_mfma_f32_4x4x1_16b_f32:
+//                            N = 4 channels per tile, so Cout = 8 is two exact N-tiles  [default]
+//   conv0_pair_mfma_kernel   conv0 on v_mfma_f32_16x16x4_f32 with the N dimension widened to two
+//                            x-adjacent outputs x 8 channels ("pair", Toeplitz-expanded weights);
+//                            conv0_pair_mfma8_kernel is its 8-wave split-K variant  [opt-in]
+//   convg_mfma_kernel        conv1..conv6 (stride 1 / 2, Cout multiple of 16) on 16x16x4
+//   deconvg_mfma_kernel      conv7 / conv9 / conv11 (+ skip) on 16x16x4, gather form over the input
+// plus the host-side packers that lay the BN-folded weights out in per-lane fragment order.
+// All kernels share one scheme: K is processed in chunks of 8 input channels = one plane of the
+// C8-planar input; per chunk the block's halo tile of that plane is staged in LDS (voxel stride /
+// row pitch chosen so the A-fragment ds_read_b128 are conflict-free) while the previous chunk's
+// MFMAs run; the global loads are unconditional so hipcc keeps counted vmcnt waits.
 //
-// GEMM shape.  Cout = 8 would fill only half of the MFMA's 16 columns, so the N dimension is
-// widened to  n = (j, co)  with j in {0,1} selecting one of two x-adjacent outputs ("pair"):
+// The pair formulation (used by conv0_pair_* here and by the 16-bit and fused kernels):
+// Cout = 8 would fill only half of the MFMA's 16 columns, so n = (j, co) with j in {0,1} selecting
+// one of two x-adjacent outputs:
 //     M : output voxel pairs (z, y, xp)            16 pairs (32 voxels along x) per MFMA tile
 //     N : 16 = 2 outputs of the pair x 8 channels
 //     K : (kz, ky, kx', ci) with kx' in 0..3 spanning the 4 input columns a pair touches
 //     A[m][k] = in[z+kz-1][y+ky-1][2*xp+kx'-1][ci]
 //     B[k][n] = w[kz][ky][kx'-j][ci][co]  if 0 <= kx'-j <= 2 else 0    (Toeplitz-expanded weights)
 // 3/4 of the MFMA work is useful (K grows 27 -> 36 taps) instead of 1/2 with zero-padded columns.
-//
-// Blocking.  One block (256 threads, 4 waves) produces a 2(z) x 8(y) x 32(x) output tile.  K is
-// processed in 4 chunks of 8 input channels = one plane of the C8-planar input: per chunk the
-// 4 x 10 x 34 halo tile of that plane is staged in LDS (48-byte voxel stride: conflict-free
-// ds_read_b128 for the pair-strided A fragments), and the chunk's B panel (18 k-steps x 16 B per
-// lane, pre-packed in lane order by mvs_pack_weights) is held in registers (weight-stationary)
-// while the wave streams its 4 M-tiles' A fragments from LDS: one ds_read_b128 feeds 4 MFMAs.
-// LDS use is 65 KB per block -> 2 blocks per CU, so one block's fill overlaps the other's MFMAs.
+// conv0 blocking: one block (256 threads, 4 waves) produces a 2(z) x 8(y) x 32(x) output tile from
+// a 4 x 10 x 34 halo tile per chunk (48-byte voxel stride); 65-72 KB of LDS -> 2 blocks per CU.
 #include <cstdlib>
 
 #include "mvs_internal.h"
