@@ -371,18 +371,33 @@ __global__ __launch_bounds__(512, 4) void conv0_pair_mfma8_kernel(
 // live in LDS next to the tile: every (tap, half) step is 2 A reads + 2 broadcast B reads
 // (ds_read_b128) feeding 16 MFMAs.
 // ---------------------------------------------------------------------------------------------
-namespace c0 {
+// Tile depth / block size of the 4x4x1 kernel (compile-time knobs for A/B builds):
+//   C0Q_TZ = 2, 256 threads: 72 KB LDS, 2 blocks per CU            [default]
+//   C0Q_TZ = 4, 512 threads: 105 KB LDS, 1 block per CU, halo ratio 2.0 instead of 2.66
+#ifndef C0Q_TZ
+#define C0Q_TZ 2
+#endif
+namespace c0q {
+constexpr int TZ = C0Q_TZ, TY = 8, TX = 32;
+constexpr int THREADS = 128 * TZ;                     // one wave per (z slice, 4 rows)
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+constexpr int VS = 12;
+constexpr int TILE_FLOATS = HZ * HY * HX * VS;
+constexpr int NPIECE = HZ * HY * HX * 2;
+constexpr int PIECES_PER_THREAD = (NPIECE + THREADS - 1) / THREADS;
 constexpr int BQ_FLOATS = 27 * 2 * 2 * 4 * 4;  // per chunk
-}
+constexpr int WPIECES = BQ_FLOATS / 4;         // 432 16-byte pieces of weights per chunk
+constexpr int WPT = (WPIECES + THREADS - 1) / THREADS;
+}  // namespace c0q
 
 template <int DT>
-__global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
+__global__ __launch_bounds__(c0q::THREADS, 2) void conv0_4x4_mfma_kernel(
     const void* __restrict__ x,      // [4][D][H][W][8] storage dtype DT
     const float* __restrict__ bq,    // [4 chunks][27 taps][2 halves][2 nt][4 j][4 k]
     const float* __restrict__ bias,  // [8]
     void* __restrict__ y,            // [D][H][W][8] storage dtype DT
     int D, int H, int W) {
-    using namespace c0;
+    using namespace c0q;
     __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + BQ_FLOATS];
     float* wlds = tile + TILE_FLOATS;
 
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
     unsigned inside = 0;
 #pragma unroll
     for (int i = 0; i < PIECES_PER_THREAD; ++i) {
-        const int p = tid + i * 256;
+        const int p = tid + i * THREADS;
         const int half = p & 1, v = p >> 1;
         const int hx = v % HX, t = v / HX;
         const int hy = t % HY, hz = t / HY;
@@ -425,16 +440,15 @@ __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
         for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 stg[PIECES_PER_THREAD];
-    f32x4 wst[2];
-    constexpr int WPIECES = BQ_FLOATS / 4;  // 432 16-byte pieces of weights per chunk
+    f32x4 wst[WPT];
 #define MVS_LOAD_A(C)                                                                         \
     {                                                                                         \
         const size_t plane = (size_t)(C) * V * 8;                                             \
         _Pragma("unroll") for (int i = 0; i < PIECES_PER_THREAD; ++i)                         \
             stg[i] = St<DT>::load4(x, plane + goff[i]);                                       \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(bq) + (size_t)(C) * WPIECES;       \
-        wst[0] = wsrc[tid];                                                                   \
-        wst[1] = wsrc[min(tid + 256, WPIECES - 1)];                                           \
+        _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                       \
+            wst[i] = wsrc[min(tid + i * THREADS, WPIECES - 1)];                               \
     }
 #define MVS_STORE_A()                                                                         \
     {                                                                                         \
@@ -442,8 +456,9 @@ __global__ __launch_bounds__(256, 2) void conv0_4x4_mfma_kernel(
             if (loff[i] >= 0)                                                                 \
                 *reinterpret_cast<f32x4*>(tile + loff[i]) =                                   \
                     ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};              \
-        reinterpret_cast<f32x4*>(wlds)[tid] = wst[0];                                         \
-        if (tid + 256 < WPIECES) reinterpret_cast<f32x4*>(wlds)[tid + 256] = wst[1];          \
+        _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                       \
+            if (tid + i * THREADS < WPIECES)                                                  \
+                reinterpret_cast<f32x4*>(wlds)[tid + i * THREADS] = wst[i];                   \
     }
 
     MVS_LOAD_A(0)
@@ -513,7 +528,7 @@ void pack_conv0_4x4_weights(const float* wfold, float* bq) {
 template <int DT>
 static int run_conv0_4x4(const void* x, void* y, const float* bq, const float* bias, int D, int H, int W,
                          int nb, hipStream_t s) {
-    conv0_4x4_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bq, bias, y, D, H, W);
+    conv0_4x4_mfma_kernel<DT><<<nb, c0q::THREADS, 0, s>>>(x, bq, bias, y, D, H, W);
     return check_hip(hipGetLastError(), "conv0_4x4_mfma launch");
 }
 
@@ -524,6 +539,7 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, 
         return fail(MVS_ERR_BAD_SHAPE, "conv0_mfma: plane of %zu elements exceeds 31-bit offsets",
                     (size_t)D * H * W * 8);
     const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+    const int nbq = ((W + c0q::TX - 1) / c0q::TX) * ((H + c0q::TY - 1) / c0q::TY) * ((D + c0q::TZ - 1) / c0q::TZ);
     static const bool eight_waves = [] {  // MVS_CONV0_8W=1: the 512-thread split-K variant (A/B runs;
         const char* e = getenv("MVS_CONV0_8W");  // measured slower: 0.69 vs 0.64 ms at cfg2)
         return e && e[0] == '1';
@@ -532,7 +548,7 @@ int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, 
         const char* e = getenv("MVS_CONV0_PAIR");
         return e && e[0] == '1';
     }();
-    if (!pair_kernel && !eight_waves) { MVS_DISPATCH_DTYPE(dtype, (run_conv0_4x4<DT>(x, y, bq, bias, D, H, W, nb, s))) }
+    if (!pair_kernel && !eight_waves) { MVS_DISPATCH_DTYPE(dtype, (run_conv0_4x4<DT>(x, y, bq, bias, D, H, W, nbq, s))) }
     if (dtype != MVS_F32)
         return fail(MVS_ERR_BAD_DTYPE, "the opt-in conv0 variants are fp32-storage only (dtype %d)", dtype);
     if (!eight_waves)
