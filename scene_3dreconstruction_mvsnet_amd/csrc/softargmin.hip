@@ -7,7 +7,7 @@
 //                             confidence = sum4[idx] = p[idx-1]+p[idx]+p[idx+1]+p[idx+2]
 //
 // cost is [D][h][w] fp32: consecutive lanes = consecutive pixels, so every depth row is read
-// fully coalesced.  A block owns 32 pixels; its 256 threads split D into 8 slices, each doing an
+// fully coalesced.  A block owns 16 pixels; its 256 threads split D into 16 slices, each doing an
 // online softmax (running max / sum / weighted sums), merged through LDS.  HBM-bound:
 // algorithmic bytes = D*h*w*4 + 2*h*w*4.
 #include "mvs_internal.h"
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
                                                               float* __restrict__ depth,
                                                               float* __restrict__ conf, int D,
                                                               int hw) {
-    constexpr int PIX = 32, NS = 8;  // pixels per block, depth slices (256 threads)
+    constexpr int PIX = 16, NS = 16;  // pixels per block, depth slices (256 threads)
     __shared__ float s_m[NS][PIX], s_s[NS][PIX], s_d[NS][PIX], s_i[NS][PIX];
     const int lane = threadIdx.x & (PIX - 1), slice = threadIdx.x / PIX;
     const int p = blockIdx.x * PIX + lane;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s) {
     const int hw = h * w;
-    softargmin_conf_kernel<<<(hw + 31) / 32, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+    softargmin_conf_kernel<<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
     return check_hip(hipGetLastError(), "softargmin launch");
 }
 
