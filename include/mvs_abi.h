@@ -143,6 +143,34 @@ int mvs_homo_warp(const float* src_fea, const float* rt, const float* depth_valu
 int mvs_depth_regression(const float* p, const float* depth_values, float* depth_out, int D,
                          int h, int w, void* stream);
 
+/* ---- depth-map filter / fusion (reference eval.py:508-585, 620-705, 253-275) ----
+ * Replaces the numpy + cv2.remap loops of reproject_with_depth / check_geometric_consistency /
+ * the per-reference-view body of filter_depth, for all reference views of a scan in one launch.
+ *
+ * mvs_filter_compose (HOST pointers only, no GPU work): forms the float32 camera products the
+ *   reference forms with np.linalg.inv / np.matmul on float32 inputs.
+ *     intrinsics [V][9], extrinsics [V][16] row-major (read_camera_parameters, eval.py:89-104)
+ *     ref_idx [R]; src_idx [R][S] with -1 for "no view" (pair.txt rows may be ragged)
+ *     ref_mats  [R][30]   = inv(K_ref)[9] | K_ref[9] | inv(E_ref[:3,:3])[9] | E_ref[:3,3][3]
+ *     pair_mats [R][S][42] = (E_src inv(E_ref))[:3][12] | K_src[9] | inv(K_src)[9] | (E_ref inv(E_src))[:3][12]
+ * mvs_filter_depth (DEVICE pointers): depth, conf fp32 [V][h][w]; ref_mats / pair_mats / ref_idx /
+ *   src_idx as above but in device memory.  Thresholds = eval.py:46-49 (--photomask, --geomask,
+ *   --condmask_pixel, --condmask_depth).  Outputs, per reference view r:
+ *     geo_sum   int32  [R][h][w]     number of source views that agree           (eval.py:694)
+ *     depth_avg double [R][h][w]     (sum of agreeing reprojected depths + d_ref)/(geo_sum+1) (699)
+ *     masks     uint8  [R][3][h][w]  photo, geo, final as 0/1                    (660, 702, 706)
+ *     xyz_world double [R][h*w][3]   depth2pts_np(depth_avg, K_ref, E_ref)       (752, 253-265)
+ *   Selecting xyz_world[final] and the colours (eval.py:753-759) stays with the caller. */
+#define MVS_FILTER_REF_FLOATS 30
+#define MVS_FILTER_PAIR_FLOATS 42
+int mvs_filter_compose(const float* intrinsics, const float* extrinsics, const int* ref_idx,
+                       const int* src_idx, int V, int R, int S, float* ref_mats, float* pair_mats);
+int mvs_filter_depth(const float* depth, const float* conf, const float* ref_mats,
+                     const float* pair_mats, const int* ref_idx, const int* src_idx, int V, int R,
+                     int S, int h, int w, double photomask, int geomask, double condmask_pixel,
+                     double condmask_depth, int* geo_sum, double* depth_avg, unsigned char* masks,
+                     double* xyz_world, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

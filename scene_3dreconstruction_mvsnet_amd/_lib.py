@@ -43,6 +43,7 @@ SYMBOLS = (
     "mvs_abi_version", "mvs_last_error_string", "mvs_query_workspace", "mvs_query_weights_blob",
     "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_warp_conv0", "mvs_costreg_forward",
     "mvs_conv_layer", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
+    "mvs_filter_compose", "mvs_filter_depth",
 )
 
 _lock = threading.Lock()
@@ -92,6 +93,10 @@ def load():
                                         _i, _i, _i, _i, _i, _i, _vp]
         lib.mvs_homo_warp.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
         lib.mvs_depth_regression.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
+        lib.mvs_filter_compose.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]
+        _d = ctypes.c_double
+        lib.mvs_filter_depth.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                         _d, _i, _d, _d, _vp, _vp, _vp, _vp, _vp]
         for name in SYMBOLS:
             if name not in ("mvs_last_error_string",):
                 getattr(lib, name).restype = _i
@@ -286,3 +291,57 @@ def from_c8(t: torch.Tensor) -> torch.Tensor:
     """C8-planar [C/8,D,h,w,8] -> [C,D,h,w]."""
     P, D, h, w, _ = t.shape
     return t.permute(0, 4, 1, 2, 3).reshape(P * 8, D, h, w).contiguous()
+
+
+FILTER_REF_FLOATS, FILTER_PAIR_FLOATS = 30, 42
+
+
+def filter_compose(intrinsics, extrinsics, ref_idx, src_idx):
+    """Host-side float32 camera products for mvs_filter_depth (numpy arrays in / out).
+
+    intrinsics [V,3,3], extrinsics [V,4,4] float32; ref_idx [R] int32; src_idx [R,S] int32 (-1 pad).
+    """
+    import numpy as np
+    K = np.ascontiguousarray(intrinsics, np.float32).reshape(-1, 9)
+    E = np.ascontiguousarray(extrinsics, np.float32).reshape(-1, 16)
+    ref = np.ascontiguousarray(ref_idx, np.int32)
+    src = np.ascontiguousarray(src_idx, np.int32)
+    if K.shape[0] != E.shape[0] or src.ndim != 2 or src.shape[0] != ref.shape[0]:
+        raise RuntimeError(f"filter_compose: inconsistent shapes K{K.shape} E{E.shape} ref{ref.shape} src{src.shape}")
+    V, R, S = K.shape[0], ref.shape[0], src.shape[1]
+    ref_mats = np.empty((R, FILTER_REF_FLOATS), np.float32)
+    pair_mats = np.empty((R, S, FILTER_PAIR_FLOATS), np.float32)
+    check(load().mvs_filter_compose(K.ctypes.data, E.ctypes.data, ref.ctypes.data, src.ctypes.data,
+                                    V, R, S, ref_mats.ctypes.data, pair_mats.ctypes.data))
+    return ref_mats, pair_mats
+
+
+def filter_depth(depth, conf, ref_mats, pair_mats, ref_idx, src_idx, photomask=0.8, geomask=3,
+                 condmask_pixel=1.0, condmask_depth=0.01):
+    """Device tensors in, device tensors out: geo_sum int32 [R,h,w], depth_avg float64 [R,h,w],
+    masks uint8 [R,3,h,w] (photo, geo, final), xyz_world float64 [R,h*w,3]."""
+    depth = _dev_f32(depth, "depth")
+    conf = _dev_f32(conf, "conf")
+    dev = depth.device
+    if depth.dim() != 3 or conf.shape != depth.shape:
+        raise RuntimeError(f"filter_depth: depth {tuple(depth.shape)} / conf {tuple(conf.shape)} must both be [V,h,w]")
+    V, h, w = depth.shape
+    ref_mats = _dev_f32(ref_mats, "ref_mats")
+    pair_mats = _dev_f32(pair_mats, "pair_mats")
+    if ref_idx.dtype != torch.int32 or src_idx.dtype != torch.int32 or not ref_idx.is_cuda or not src_idx.is_cuda:
+        raise RuntimeError("filter_depth: ref_idx / src_idx must be int32 tensors on the GPU")
+    R, S = src_idx.shape
+    if tuple(ref_mats.shape) != (R, FILTER_REF_FLOATS) or tuple(pair_mats.shape) != (R, S, FILTER_PAIR_FLOATS) \
+            or ref_idx.numel() != R:
+        raise RuntimeError("filter_depth: ref_mats / pair_mats / ref_idx do not match src_idx's [R,S]")
+    ref_idx, src_idx = ref_idx.contiguous(), src_idx.contiguous()
+    geo = torch.empty((R, h, w), dtype=torch.int32, device=dev)
+    avg = torch.empty((R, h, w), dtype=torch.float64, device=dev)
+    masks = torch.empty((R, 3, h, w), dtype=torch.uint8, device=dev)
+    xyz = torch.empty((R, h * w, 3), dtype=torch.float64, device=dev)
+    check(load().mvs_filter_depth(depth.data_ptr(), conf.data_ptr(), ref_mats.data_ptr(),
+                                  pair_mats.data_ptr(), ref_idx.data_ptr(), src_idx.data_ptr(),
+                                  V, R, S, h, w, float(photomask), int(geomask), float(condmask_pixel),
+                                  float(condmask_depth), geo.data_ptr(), avg.data_ptr(), masks.data_ptr(),
+                                  xyz.data_ptr(), _stream(dev)))
+    return geo, avg, masks, xyz

@@ -5,6 +5,7 @@ Per sample it runs the drop-in MVSNet forward and writes, under `outdir`:
     {scan}/depth_est/{view:08d}.pfm     <- outputs["depth"][b]                  (eval.py:387)
     {scan}/confidence/{view:08d}.pfm    <- outputs["photometric_confidence"][b] (eval.py:392)
     {scan}/cams/{view:08d}_cam.txt      <- write_cam(K, E, ["000","2.5","",""]) (eval.py:396,107-126)
+    {scan}/images/{view:08d}.png        <- uint8(ref image * 255), RGB          (eval.py:346-350)
 with `filename = "{scan}/{{}}/{view:08d}{{}}"` as the reference datasets produce it
 (datasets/dataloader_eval.py:176).  Not reproduced (flagged, not silently changed): the PNG previews
 (eval.py:388,393, need cv2), the point-cloud accumulation (eval.py:409-440, needs open3d).
@@ -21,6 +22,7 @@ import threading
 
 import numpy as np
 import torch
+from PIL import Image
 
 from . import data_io, sharding
 
@@ -48,11 +50,15 @@ def _writer(q: "queue.Queue"):
         job = q.get()
         if job is None:
             return
-        outdir, filename, depth, conf, K, E = job
+        outdir, filename, depth, conf, K, E, img = job
         depth_fn, conf_fn = data_io.depth_map_paths(outdir, filename)
         cam_fn = os.path.join(outdir, filename.format("cams", "_cam.txt"))
-        for fn in (depth_fn, conf_fn, cam_fn):
+        img_fn = os.path.join(outdir, filename.format("images", ".png"))
+        for fn in (depth_fn, conf_fn, cam_fn, img_fn):
             os.makedirs(os.path.dirname(fn), exist_ok=True)
+        if img is not None:
+            # eval.py:346-350: the two BGR<->RGB swaps there cancel, the file holds uint8(img*255) RGB
+            Image.fromarray(np.uint8(np.transpose(img, (1, 2, 0)) * 255)).save(img_fn)
         data_io.save_pfm(depth_fn, depth)
         data_io.save_pfm(conf_fn, conf)
         if K is not None and E is not None:
@@ -85,7 +91,7 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
                 conf = out["photometric_confidence"][0].detach().cpu().numpy().copy()
                 K = np.asarray(s["intrinsics"][0]) if "intrinsics" in s else None
                 E = np.asarray(s["extrinsics"][0]) if "extrinsics" in s else None
-                q.put((outdir, s["filename"], depth, conf, K, E))
+                q.put((outdir, s["filename"], depth, conf, K, E, np.asarray(s["imgs"][0], np.float32)))
     finally:
         q.put(None)
         th.join()
