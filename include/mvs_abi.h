@@ -171,6 +171,36 @@ int mvs_filter_depth(const float* depth, const float* conf, const float* ref_mat
                      double condmask_depth, int* geo_sum, double* depth_avg, unsigned char* masks,
                      double* xyz_world, void* stream);
 
+/* ---- FeatureNet (reference models/mvsnet.py:10-30, block models/module.py:6-13)
+ * and the whole MVSNet.forward of one batch item from images (models/mvsnet.py:103-239, eval).
+ *
+ * mvs_pack_feature_weights (HOST pointers): conv_weights[8] = feature.conv0..conv6.conv.weight and
+ *   feature.feature.weight, each [Cout][Cin][k][k]; bn_params[7*4] = per ConvBnReLU block
+ *   (bn.weight, bn.bias, bn.running_mean, bn.running_var); feature_bias [32].  Folds eval BatchNorm
+ *   into the weights and lays them out as MFMA panels; blob_out is host memory of
+ *   mvs_query_feature_blob() bytes that the caller then copies to the device.
+ * mvs_feature_net: imgs dev fp32 [N][3][H][W] -> feats_out dev fp32 [N][32][H/4][W/4] (NCHW, as
+ *   FeatureNet.forward returns them); workspace of mvs_query_feature_workspace(N,H,W) bytes.
+ * mvs_feature_layer: one layer (0..6 = conv0..conv6, 7 = feature) for per-layer parity tests;
+ *   x = NCHW image [N][3][Hi][Wi] for layer 0, else C8-planar [Cin/8][N][Hi][Wi][8]; y C8-planar.
+ * mvs_forward_images: FeatureNet + mvs_depth_infer with the features handed over in the private
+ *   C8-planar layout (no NCHW round trip); H, W multiples of 32; workspace of
+ *   mvs_query_forward_workspace(N,H,W,D,dtype) bytes. */
+#define MVS_FEATURE_LAYERS 8
+int mvs_query_feature_blob(size_t* bytes);
+int mvs_pack_feature_weights(const float* const* conv_weights, const float* const* bn_params,
+                             const float* feature_bias, float eps, void* blob_out, size_t blob_bytes);
+int mvs_query_feature_workspace(int N, int H, int W, size_t* bytes);
+int mvs_feature_layer(int layer, const float* x, float* y, const void* feature_blob, int N, int Hi, int Wi,
+                      void* stream);
+int mvs_feature_net(const float* imgs, const void* feature_blob, float* feats_out, void* workspace,
+                    size_t workspace_bytes, int N, int H, int W, void* stream);
+int mvs_query_forward_workspace(int N, int H, int W, int D, int dtype, size_t* bytes);
+int mvs_forward_images(const float* imgs, const float* proj, const float* depth_values,
+                       const void* feature_blob, const void* weights_blob, float* depth_out,
+                       float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                       int D, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,40 @@ def conv3d(x, w, bias=None, bn=None, stride=1, relu=True):
     return y
 
 
+def conv2d(x, w, bias=None, bn=None, stride=1, relu=True):
+    """Conv2d k x k, pad k//2 (+bias)(+BN eval)(+ReLU): x [Cin,H,W], w [Cout,Cin,k,k]
+    (models/module.py:6-13)."""
+    x = _f32(x)
+    w = _f32(w)
+    Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    assert w.shape == (Cout, Cin, k, k)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = np.empty((Cout, Ho, Wo), np.float32)
+    g, b, m, v = (None,) * 4 if bn is None else [_f32(t) for t in bn]
+    bias = None if bias is None else _f32(bias)
+    lib().orc_conv2d(_p(x), _p(w), _p(bias), _p(g), _p(b), _p(m), _p(v), _p(y),
+                     Cin, Cout, H, W, k, stride, int(relu))
+    return y
+
+
+# (name, stride) of FeatureNet's ConvBnReLU blocks, models/mvsnet.py:15-22
+FEATURE_BLOCKS = (("conv0", 1), ("conv1", 1), ("conv2", 2), ("conv3", 1), ("conv4", 1), ("conv5", 2),
+                  ("conv6", 1))
+
+
+def feature_net(img, sd, prefix="feature."):
+    """FeatureNet.forward (models/mvsnet.py:26-30) for one image [3,H,W] -> [32,H/4,W/4];
+    `sd` = state dict of the whole model (keys `feature.convN.conv.weight`, `feature.convN.bn.*`,
+    `feature.feature.{weight,bias}`)."""
+    x = _f32(img)
+    for name, stride in FEATURE_BLOCKS:
+        bn = [sd[f"{prefix}{name}.bn.{k}"] for k in ("weight", "bias", "running_mean", "running_var")]
+        x = conv2d(x, sd[f"{prefix}{name}.conv.weight"], bn=bn, stride=stride, relu=True)
+    return conv2d(x, sd[f"{prefix}feature.weight"], bias=sd[f"{prefix}feature.bias"], relu=False)
+
+
 def deconv3d(x, w, bn=None, relu=True):
     """ConvTranspose3d k3 s2 p1 op1 (+BN eval)(+ReLU): x [Cin,D,H,W], w [Cin,Cout,3,3,3]."""
     x = _f32(x)

@@ -44,6 +44,8 @@ SYMBOLS = (
     "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_warp_conv0", "mvs_costreg_forward",
     "mvs_conv_layer", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
     "mvs_filter_compose", "mvs_filter_depth",
+    "mvs_query_feature_blob", "mvs_pack_feature_weights", "mvs_query_feature_workspace",
+    "mvs_feature_layer", "mvs_feature_net", "mvs_query_forward_workspace", "mvs_forward_images",
 )
 
 _lock = threading.Lock()
@@ -93,6 +95,15 @@ def load():
                                         _i, _i, _i, _i, _i, _i, _vp]
         lib.mvs_homo_warp.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
         lib.mvs_depth_regression.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp]
+        lib.mvs_query_feature_blob.argtypes = [ctypes.POINTER(_sz)]
+        lib.mvs_pack_feature_weights.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp,
+                                                 ctypes.c_float, _vp, _sz]
+        lib.mvs_query_feature_workspace.argtypes = [_i, _i, _i, ctypes.POINTER(_sz)]
+        lib.mvs_feature_layer.argtypes = [_i, _vp, _vp, _vp, _i, _i, _i, _vp]
+        lib.mvs_feature_net.argtypes = [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]
+        lib.mvs_query_forward_workspace.argtypes = [_i, _i, _i, _i, _i, ctypes.POINTER(_sz)]
+        lib.mvs_forward_images.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                           _i, _i, _i, _i, _i, _vp]
         lib.mvs_filter_compose.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]
         _d = ctypes.c_double
         lib.mvs_filter_depth.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
@@ -345,3 +356,114 @@ def filter_depth(depth, conf, ref_mats, pair_mats, ref_idx, src_idx, photomask=0
                                   float(condmask_depth), geo.data_ptr(), avg.data_ptr(), masks.data_ptr(),
                                   xyz.data_ptr(), _stream(dev)))
     return geo, avg, masks, xyz
+
+
+# ---- FeatureNet (reference models/mvsnet.py:10-30) -------------------------------------------
+# (cin, cout, k, stride) of conv0..conv6 and the final `feature` Conv2d
+FEATURE_LAYERS = ((3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 16, 3, 1),
+                  (16, 32, 5, 2), (32, 32, 3, 1), (32, 32, 3, 1))
+FEATURE_WEIGHT_KEYS = tuple([f"conv{i}.conv.weight" for i in range(7)] + ["feature.weight"])
+
+
+def query_feature_blob() -> int:
+    n = _sz(0)
+    check(load().mvs_query_feature_blob(ctypes.byref(n)))
+    return int(n.value)
+
+
+def pack_feature_weights(state: dict, eps: float = 1e-5) -> torch.Tensor:
+    """BN-fold + re-layout FeatureNet's parameters into MFMA panels (host, uint8).
+    `state` maps names relative to `feature.` to CPU float32 tensors/arrays."""
+    import numpy as np
+    keep = []
+
+    def arr(key, shape):
+        a = state[key]
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise RuntimeError(f"{key}: shape {tuple(a.shape)} != expected {tuple(shape)}")
+        keep.append(a)
+        return a.ctypes.data
+
+    convs = (_vp * 8)()
+    for l, key in enumerate(FEATURE_WEIGHT_KEYS):
+        ci, co, k, _ = FEATURE_LAYERS[l]
+        convs[l] = arr(key, (co, ci, k, k))
+    bns = (_vp * 28)()
+    for l in range(7):
+        co = FEATURE_LAYERS[l][1]
+        for j, suffix in enumerate(("weight", "bias", "running_mean", "running_var")):
+            bns[4 * l + j] = arr(f"conv{l}.bn.{suffix}", (co,))
+    bias = arr("feature.bias", (32,))
+    nbytes = query_feature_blob()
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    check(load().mvs_pack_feature_weights(convs, bns, bias, ctypes.c_float(eps), blob.data_ptr(), nbytes))
+    return blob
+
+
+def query_feature_workspace(N, H, W) -> int:
+    n = _sz(0)
+    check(load().mvs_query_feature_workspace(N, H, W, ctypes.byref(n)))
+    return int(n.value)
+
+
+def query_forward_workspace(N, H, W, D, dtype=MVS_F32) -> int:
+    n = _sz(0)
+    check(load().mvs_query_forward_workspace(N, H, W, D, dtype, ctypes.byref(n)))
+    return int(n.value)
+
+
+def feature_layer(layer, x, fblob):
+    """One FeatureNet layer on the GPU.  x: NCHW images [N,3,H,W] for layer 0, otherwise C8-planar
+    [Cin/8,N,H,W,8]; returns C8-planar [Cout/8,N,Ho,Wo,8]."""
+    x = _dev_f32(x, "x")
+    ci, co, k, s = FEATURE_LAYERS[layer]
+    if layer == 0:
+        N, c, H, W = x.shape
+        if c != 3:
+            raise RuntimeError(f"feature layer 0 wants [N,3,H,W] images, got {tuple(x.shape)}")
+    else:
+        pl, N, H, W, e = x.shape
+        if pl * e != ci or e != 8:
+            raise RuntimeError(f"feature layer {layer} wants C8-planar input with {ci} channels, got {tuple(x.shape)}")
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    y = torch.empty((co // 8, N, Ho, Wo, 8), dtype=torch.float32, device=x.device)
+    check(load().mvs_feature_layer(layer, x.data_ptr(), y.data_ptr(), fblob.data_ptr(), N, H, W,
+                                   _stream(x.device)))
+    return y
+
+
+def feature_net(imgs, fblob, workspace=None):
+    """FeatureNet.forward on the GPU: imgs [N,3,H,W] fp32 -> [N,32,H/4,W/4] fp32 (NCHW)."""
+    imgs = _dev_f32(imgs, "imgs")
+    if imgs.dim() != 4 or imgs.shape[1] != 3:
+        raise RuntimeError(f"feature_net wants [N,3,H,W] images, got {tuple(imgs.shape)}")
+    N, _, H, W = imgs.shape
+    nbytes = query_feature_workspace(N, H, W)
+    if workspace is None:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=imgs.device)
+    h4, w4 = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+    out = torch.empty((N, 32, h4, w4), dtype=torch.float32, device=imgs.device)
+    check(load().mvs_feature_net(imgs.data_ptr(), fblob.data_ptr(), out.data_ptr(), workspace.data_ptr(),
+                                 workspace.numel(), N, H, W, _stream(imgs.device)))
+    return out
+
+
+def forward_images(imgs, proj, depth_values, fblob, blob, workspace, depth_out, conf_out, dtype=MVS_F32):
+    """MVSNet.forward of one batch item from images: imgs [N,3,H,W], proj [N,4,4], depth_values [D]."""
+    imgs = _dev_f32(imgs, "imgs")
+    proj = _dev_f32(proj, "proj_matrices")
+    depth_values = _dev_f32(depth_values, "depth_values")
+    N, c, H, W = imgs.shape
+    if c != 3 or tuple(proj.shape) != (N, 4, 4):
+        raise RuntimeError(f"forward_images: imgs {tuple(imgs.shape)} / proj {tuple(proj.shape)}")
+    D = depth_values.numel()
+    if tuple(depth_out.shape) != (H // 4, W // 4) or tuple(conf_out.shape) != (H // 4, W // 4) \
+            or not depth_out.is_contiguous() or not conf_out.is_contiguous():
+        raise RuntimeError("forward_images: depth_out / conf_out must be contiguous [H/4, W/4] float32")
+    check(load().mvs_forward_images(imgs.data_ptr(), proj.data_ptr(), depth_values.data_ptr(),
+                                    fblob.data_ptr(), blob.data_ptr(), depth_out.data_ptr(),
+                                    conf_out.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                    N, H, W, D, dtype, _stream(imgs.device)))

@@ -1,0 +1,307 @@
+// featnet.hip -- FeatureNet (reference models/mvsnet.py:10-30; block ConvBnReLU of
+// models/module.py:6-13) as fp32-MFMA implicit-GEMM 2-D convolutions.
+//
+//   conv0 3->8 k3 | conv1 8->8 k3 | conv2 8->16 k5 s2 | conv3,4 16->16 k3 | conv5 16->32 k5 s2 |
+//   conv6 32->32 k3 | feature 32->32 k3 (+bias, no BN / ReLU)             BN (eval) folded on the host
+//
+// Layout: every activation is C8-planar over the N views, [C/8][N][H][W][8] -- exactly the layout
+// the warp kernel gathers from, so the last layer writes the path's feature buffer directly and the
+// NCHW -> C8 transpose of the PyTorch hand-off disappears.  The input images are read as NCHW
+// [N][3][H][W] by conv0's staging code (channels 3..7 of its only K-chunk are zero).
+//
+// Kernel scheme (same as conv3d_mfma.hip, one dimension less):
+//   M : output pixels, one MFMA tile = 2(y) x 8(x)          N : 16 output channels per N-tile
+//   K : (tap, ci) in chunks of 8 input channels (one plane); a k-step of 16 = 2 taps x 8 channels,
+//       9 taps -> 5 k-steps, 25 taps -> 13 k-steps
+//   block = 4 waves = NT N-tiles x MG M-groups, block tile BY x BX M-tiles; per chunk the halo tile
+//   is staged in LDS (voxel stride 32 B for stride 1, 48 B for stride 2; row pitch a multiple of 8
+//   voxels: conflict-free ds_read_b128), the (chunk, N-tile) B panel lives in registers; staging of
+//   chunk c+1 overlaps the MFMAs of chunk c with unconditional loads (counted vmcnt).
+// Cout = 8 layers (conv0, conv1) run with a half-empty N-tile: they are HBM-bound at full
+// resolution (2 x 52 MB at 5 x 512 x 640), not MFMA-bound.
+#include "mvs_internal.h"
+#include "storage.h"
+
+namespace mvs {
+
+template <int CIN, int COUT, int KW, int S, int BY, int BX>
+struct FConv {
+    static constexpr int NCH = (CIN + 7) / 8;
+    static constexpr int NT = (COUT + 15) / 16;
+    static constexpr int MG = 4 / NT;
+    static constexpr int MT = BY * BX;
+    static constexpr int MPW = MT / MG;
+    static constexpr int TAPS = KW * KW;
+    static constexpr int KS = (TAPS + 1) / 2;
+    static constexpr int PAD = KW / 2;
+    static constexpr int VS = (S == 1) ? 8 : 12;
+    static constexpr int HY = (2 * BY - 1) * S + KW, HX = (8 * BX - 1) * S + KW;
+    static constexpr int HXP = (HX + 7) / 8 * 8;
+    static constexpr int TILE_FLOATS = HY * HXP * VS;
+    static constexpr int NVOX = HY * HX;
+    static constexpr int NPIECE = NVOX * 2;
+    static constexpr int PPT = (NPIECE + 255) / 256;
+    static constexpr int VPT = (NVOX + 255) / 256;  // image-input staging: voxels per thread
+    static_assert(NT == 1 || NT == 2 || NT == 4, "COUT must be <= 64");
+    static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
+    static_assert(PPT <= 32, "piece mask is 32 bits");
+    static constexpr int tap_off(int tap) {  // LDS float offset of tap (ky,kx); taps >= TAPS = padding
+        const int t = tap >= TAPS ? TAPS - 1 : tap;
+        return ((t / KW) * HXP + t % KW) * VS;
+    }
+};
+
+template <int CIN, int COUT, int KW, int S, int BY, int BX, bool RELU, bool IMG_IN>
+__global__ __launch_bounds__(256) void fconv_mfma_kernel(
+    const float* __restrict__ x,     // IMG_IN ? [N][3][Hi][Wi] : [CIN/8][N][Hi][Wi][8]
+    const float* __restrict__ bp,    // [NCH][NT][KS][64][4]
+    const float* __restrict__ bias,  // [16 NT]
+    float* __restrict__ y,           // [COUT/8][N][Ho][Wo][8]
+    int N, int Hi, int Wi, int Ho, int Wo) {
+    using G = FConv<CIN, COUT, KW, S, BY, BX>;
+    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NT, mg = wave / G::NT;
+    const int nbx = (Wo + 8 * BX - 1) / (8 * BX);
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, n = blockIdx.y;
+    const int ox0 = bx * 8 * BX, oy0 = by * 2 * BY;
+    const int ix0 = ox0 * S - G::PAD, iy0 = oy0 * S - G::PAD;
+    const size_t HWi = (size_t)Hi * Wi, HWo = (size_t)Ho * Wo;
+
+    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = t / BX;
+        abase[i] = ((2 * ty + ry) * S * G::HXP + (8 * tx + rx) * S) * G::VS + (g & 1) * 4;
+    }
+    f32x4 acc[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 breg[G::KS];
+
+#define FN_LOAD_B(C)                                                                                \
+    {                                                                                               \
+        const f32x4* bsrc =                                                                         \
+            reinterpret_cast<const f32x4*>(bp) + ((size_t)((C) * G::NT + nt) * G::KS) * 64 + lane;  \
+        _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];              \
+    }
+#define FN_MFMA_CHUNK()                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) {                                          \
+        const int koff = gh ? G::tap_off(2 * ks + 1) : G::tap_off(2 * ks);                          \
+        f32x4 a[G::MPW];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < G::MPW; ++i)                                          \
+            a[i] = *reinterpret_cast<const f32x4*>(tile + abase[i] + koff);                         \
+        const f32x4 bq = breg[ks];                                                                  \
+        _Pragma("unroll") for (int i = 0; i < G::MPW; ++i)                                          \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < G::MPW; ++i)                                          \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < G::MPW; ++i)                                          \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < G::MPW; ++i)                                          \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);           \
+    }
+
+    if constexpr (IMG_IN) {
+        // one K-chunk: channels 0..2 = R,G,B of the NCHW image, 3..7 = 0
+        FN_LOAD_B(0)
+        const float* img = x + (size_t)n * 3 * HWi;
+#pragma unroll
+        for (int i = 0; i < G::VPT; ++i) {
+            const int v = tid + i * 256;
+            if (v < G::NVOX) {
+                const int hx = v % G::HX, hy = v / G::HX;
+                const int gy = iy0 + hy, gx = ix0 + hx;
+                f32x4 px = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) {
+                    const size_t o = (size_t)gy * Wi + gx;
+                    px.x = img[o];
+                    px.y = img[HWi + o];
+                    px.z = img[2 * HWi + o];
+                }
+                float* dst = tile + (hy * G::HXP + hx) * G::VS;
+                *reinterpret_cast<f32x4*>(dst) = px;
+                *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        FN_MFMA_CHUNK()
+    } else {
+        int goff[G::PPT], loff[G::PPT];
+        unsigned inside = 0;
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) {
+            const int p = tid + i * 256;
+            const int half = p & 1, v = p >> 1;
+            const int hx = v % G::HX, hy = v / G::HX;
+            const int gy = iy0 + hy, gx = ix0 + hx;
+            const bool ok = p < G::NPIECE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+            goff[i] = ok ? (int)(((size_t)gy * Wi + gx) * 8 + half * 4) : 0;
+            inside |= ok ? (1u << i) : 0u;
+            loff[i] = (p < G::NPIECE) ? (hy * G::HXP + hx) * G::VS + half * 4 : -1;
+        }
+        f32x4 stg[G::PPT];
+#define FN_LOAD_A(C)                                                                                \
+    {                                                                                               \
+        const float* plane = x + ((size_t)(C) * N + n) * HWi * 8;                                   \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            stg[i] = *reinterpret_cast<const f32x4*>(plane + goff[i]);                              \
+    }
+#define FN_STORE_A()                                                                                \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i)                                          \
+            if (loff[i] >= 0)                                                                       \
+                *reinterpret_cast<f32x4*>(tile + loff[i]) =                                         \
+                    ((inside >> i) & 1u) ? stg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};                    \
+    }
+        FN_LOAD_B(0)
+        FN_LOAD_A(0)
+        FN_STORE_A()
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < G::NCH; ++c) {
+            if (c + 1 < G::NCH) FN_LOAD_A(c + 1)
+            FN_MFMA_CHUNK()
+            if (c + 1 < G::NCH) {
+                FN_LOAD_B(c + 1)
+                __syncthreads();
+                FN_STORE_A()
+                __syncthreads();
+            }
+        }
+#undef FN_LOAD_A
+#undef FN_STORE_A
+    }
+#undef FN_LOAD_B
+#undef FN_MFMA_CHUNK
+
+    // epilogue: D layout col = lane&15 -> co = 16 nt + col; row m = 4 (lane>>4) + e -> pixel of tile
+    const int col = lane & 15, co = 16 * nt + col;
+    if (co >= COUT) return;
+    const float bv = bias[co];
+    float* yplane = y + ((size_t)(co >> 3) * N + n) * HWo * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = t / BX;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
+            if (gy < Ho && gx < Wo) {
+                const float v = acc[i][e] + bv;
+                yplane[((size_t)gy * Wo + gx) * 8] = RELU ? fmaxf(v, 0.0f) : v;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int KW, int S, int BY, int BX, bool RELU, bool IMG_IN>
+static int run_fconv(const float* x, float* y, const float* bp, const float* bias, int N, int Hi, int Wi,
+                     hipStream_t s) {
+    using G = FConv<CIN, COUT, KW, S, BY, BX>;
+    const int Ho = (Hi + 2 * G::PAD - KW) / S + 1, Wo = (Wi + 2 * G::PAD - KW) / S + 1;
+    if ((size_t)N * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "feature_net: activation plane exceeds 31-bit offsets");
+    dim3 grid(((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)), N);
+    fconv_mfma_kernel<CIN, COUT, KW, S, BY, BX, RELU, IMG_IN><<<grid, 256, 0, s>>>(x, bp, bias, y, N, Hi, Wi,
+                                                                                Ho, Wo);
+    return check_hip(hipGetLastError(), "fconv_mfma launch");
+}
+
+// one FeatureNet layer l (0..7) at input resolution Hi x Wi
+int launch_feature_layer(int l, const float* x, float* y, const float* blob, int N, int Hi, int Wi,
+                         hipStream_t s) {
+    const FeatBlob L = feat_blob_layout();
+    const float* bp = blob + L.panel_off[l];
+    const float* bias = blob + L.bias_off[l];
+    switch (l) {
+        case 0: return run_fconv<3, 8, 3, 1, 4, 4, true, true>(x, y, bp, bias, N, Hi, Wi, s);
+        case 1: return run_fconv<8, 8, 3, 1, 4, 4, true, false>(x, y, bp, bias, N, Hi, Wi, s);
+        case 2: return run_fconv<8, 16, 5, 2, 2, 4, true, false>(x, y, bp, bias, N, Hi, Wi, s);
+        case 3:
+        case 4: return run_fconv<16, 16, 3, 1, 2, 4, true, false>(x, y, bp, bias, N, Hi, Wi, s);
+        case 5: return run_fconv<16, 32, 5, 2, 2, 2, true, false>(x, y, bp, bias, N, Hi, Wi, s);
+        case 6: return run_fconv<32, 32, 3, 1, 2, 2, true, false>(x, y, bp, bias, N, Hi, Wi, s);
+        case 7: return run_fconv<32, 32, 3, 1, 2, 2, false, false>(x, y, bp, bias, N, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "feature layer %d outside [0,8)", l);
+    }
+}
+
+// images [N][3][H][W] -> C8-planar features [4][N][H/4][W/4][8]; bufA / bufB hold N*8*H*W floats each
+int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8, float* bufA, float* bufB,
+                          int N, int H, int W, hipStream_t s) {
+    const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1, H4 = (H2 - 1) / 2 + 1, W4 = (W2 - 1) / 2 + 1;
+    int st;
+    if ((st = launch_feature_layer(0, imgs, bufA, blob, N, H, W, s))) return st;
+    if ((st = launch_feature_layer(1, bufA, bufB, blob, N, H, W, s))) return st;
+    if ((st = launch_feature_layer(2, bufB, bufA, blob, N, H, W, s))) return st;
+    if ((st = launch_feature_layer(3, bufA, bufB, blob, N, H2, W2, s))) return st;
+    if ((st = launch_feature_layer(4, bufB, bufA, blob, N, H2, W2, s))) return st;
+    if ((st = launch_feature_layer(5, bufA, bufB, blob, N, H2, W2, s))) return st;
+    if ((st = launch_feature_layer(6, bufB, bufA, blob, N, H4, W4, s))) return st;
+    return launch_feature_layer(7, bufA, feats_c8, blob, N, H4, W4, s);
+}
+
+// C8-planar [C/8][N][hw][8] fp32 -> NCHW [N][C][hw] (API parity with FeatureNet.forward's output)
+__global__ __launch_bounds__(256) void c8_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int N, int C, int hw) {
+    __shared__ float tile[64][9];
+    const int n = blockIdx.y, pl = blockIdx.z, p0 = blockIdx.x * 64;
+    const int c8 = threadIdx.x & 7, q = threadIdx.x >> 3;  // 8 channels x 32 pixels per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = p0 + q + 32 * pass;
+        tile[q + 32 * pass][c8] = (p < hw) ? in[(((size_t)pl * N + n) * hw + p) * 8 + c8] : 0.f;
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 63, cc = threadIdx.x >> 6;  // 64 pixels x 4 channels per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = cc + 4 * pass;
+        if (p0 + px < hw) out[((size_t)n * C + pl * 8 + c) * hw + p0 + px] = tile[px][c];
+    }
+}
+
+int launch_c8_to_nchw(const float* in, float* out, int N, int C, int h, int w, hipStream_t s) {
+    const int hw = h * w;
+    c8_to_nchw_kernel<<<dim3((hw + 63) / 64, N, C / 8), 256, 0, s>>>(in, out, N, C, hw);
+    return check_hip(hipGetLastError(), "c8_to_nchw launch");
+}
+
+// fp32 C8-planar features -> 16-bit copy for the 16-bit gather (storage dtype modes)
+template <typename T>
+__global__ void narrow_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (T)in[i];
+}
+int launch_narrow_features(const float* in, void* out, size_t n, int dtype, hipStream_t s) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dtype == MVS_F16) narrow_kernel<_Float16><<<nb, 256, 0, s>>>(in, static_cast<_Float16*>(out), n);
+    else if (dtype == MVS_BF16) narrow_kernel<__bf16><<<nb, 256, 0, s>>>(in, static_cast<__bf16*>(out), n);
+    else return fail(MVS_ERR_BAD_DTYPE, "narrow_features: dtype %d", dtype);
+    return check_hip(hipGetLastError(), "narrow_features launch");
+}
+
+// Host-side packing of one BN-folded layer: w [cout][cin][k][k] -> bp [NCH][NT][KS][64][4]
+void pack_fconv_weights(const float* w, int cin, int cout, int k, float* bp) {
+    const int nch = (cin + 7) / 8, nt = (cout + 15) / 16, taps = k * k, ksn = (taps + 1) / 2;
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < nt; ++t)
+            for (int ks = 0; ks < ksn; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const int g = lane >> 4, n = lane & 15;
+                        const int tap = 2 * ks + (g >> 1);
+                        const int ci = 8 * c + 4 * (g & 1) + j4, co = 16 * t + n;
+                        float v = 0.0f;
+                        if (tap < taps && ci < cin && co < cout) v = w[((size_t)co * cin + ci) * taps + tap];
+                        bp[((((size_t)c * nt + t) * ksn + ks) * 64 + lane) * 4 + j4] = v;
+                    }
+}
+
+}  // namespace mvs

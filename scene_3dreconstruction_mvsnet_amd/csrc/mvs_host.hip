@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "mvs_internal.h"
 
@@ -40,6 +41,15 @@ static int check_dims(int N, int C, int D, int h, int w, int dtype) {
         return fail(MVS_ERR_BAD_SHAPE, "volume of %zu elements exceeds 32-bit indexing",
                     (size_t)D * h * w * kC);
     return MVS_OK;
+}
+
+// 16-bit modes: the feature copy is narrowed too (half the gather bytes) unless MVS_FEAT16=0
+bool feat16_gather() {
+    static const bool on = [] {
+        const char* e = getenv("MVS_FEAT16");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 
 }  // namespace mvs
@@ -125,10 +135,12 @@ int mvs_relative_proj(const float* proj, float* rt_out, int N, void* stream) {
     return launch_relative_proj(proj, rt_out, N, static_cast<hipStream_t>(stream));
 }
 
-int mvs_warp_variance(const float* feats, const float* rt, const float* depth_values,
-                      void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
-                      int h, int w, int dtype, void* stream) {
-    if (!feats || !depth_values || !var_out || !workspace || (N > 1 && !rt))
+// feats == NULL: the C8-planar feature copy (fp32, or the storage dtype when the 16-bit gather is
+// on) already sits in the workspace -- written there by FeatureNet's last layer (featnet.hip).
+static int warp_variance_impl(const float* feats, const float* rt, const float* depth_values,
+                              void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
+                              int h, int w, int dtype, void* stream) {
+    if (!depth_values || !var_out || !workspace || (N > 1 && !rt))
         return fail(MVS_ERR_NULL, "mvs_warp_variance: NULL argument");
     if (int st = check_dims(N, C, D, h, w, dtype)) return st;
     const Workspace W = workspace_layout(N, C, D, h, w, dtype);
@@ -138,17 +150,22 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
         return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
-    // 16-bit modes: the feature copy is narrowed too (half the gather bytes) unless MVS_FEAT16=0
-    static const bool feat16 = [] {
-        const char* e = getenv("MVS_FEAT16");
-        return !(e && e[0] == '0');
-    }();
-    if (feat16 && dtype != MVS_F32) {
-        if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, dtype, s)) return st;
+    if (feat16_gather() && dtype != MVS_F32) {
+        if (feats)
+            if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, dtype, s)) return st;
         return launch_warp_variance16(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
     }
-    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
+    if (feats)
+        if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
     return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
+}
+
+int mvs_warp_variance(const float* feats, const float* rt, const float* depth_values,
+                      void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
+                      int h, int w, int dtype, void* stream) {
+    if (!feats) return fail(MVS_ERR_NULL, "mvs_warp_variance: NULL argument");
+    return warp_variance_impl(feats, rt, depth_values, var_out, workspace, workspace_bytes, N, C, D, h, w,
+                              dtype, stream);
 }
 
 // CostRegNet from the variance volume, or -- var == NULL -- from an already computed conv0
@@ -238,11 +255,12 @@ int mvs_softargmin_conf(const float* cost, const float* depth_values, float* dep
                              static_cast<hipStream_t>(stream));
 }
 
-int mvs_depth_infer(const float* feats, const float* proj, const float* depth_values,
-                    const void* weights_blob, float* depth_out, float* conf_out, void* workspace,
-                    size_t workspace_bytes, int N, int C, int D, int h, int w, int dtype,
-                    void* stream) {
-    if (!feats || !proj || !depth_values || !weights_blob || !depth_out || !conf_out || !workspace)
+// feats == NULL: features already in the workspace's C8 slot (see warp_variance_impl)
+static int depth_infer_impl(const float* feats, const float* proj, const float* depth_values,
+                            const void* weights_blob, float* depth_out, float* conf_out, void* workspace,
+                            size_t workspace_bytes, int N, int C, int D, int h, int w, int dtype,
+                            void* stream) {
+    if (!proj || !depth_values || !weights_blob || !depth_out || !conf_out || !workspace)
         return fail(MVS_ERR_NULL, "mvs_depth_infer: NULL argument");
     if (int st = check_dims(N, C, D, h, w, dtype)) return st;
     const Workspace W = workspace_layout(N, C, D, h, w, dtype);
@@ -268,9 +286,9 @@ int mvs_depth_infer(const float* feats, const float* proj, const float* depth_va
         const char* e = getenv("MVS_FUSE");
         return !(e && e[0] == '1');
     }();
-    if (no_fuse) {
-        if ((st = mvs_warp_variance(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
-                                    h, w, dtype, stream)))
+    if (no_fuse || !feats) {
+        if ((st = warp_variance_impl(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
+                                     h, w, dtype, stream)))
             return st;
         if ((st = costreg_impl(var, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream))) return st;
     } else {
@@ -281,6 +299,145 @@ int mvs_depth_infer(const float* feats, const float* proj, const float* depth_va
             return st;
     }
     return mvs_softargmin_conf(cost, depth_values, depth_out, conf_out, D, h, w, stream);
+}
+
+int mvs_depth_infer(const float* feats, const float* proj, const float* depth_values,
+                    const void* weights_blob, float* depth_out, float* conf_out, void* workspace,
+                    size_t workspace_bytes, int N, int C, int D, int h, int w, int dtype,
+                    void* stream) {
+    if (!feats) return fail(MVS_ERR_NULL, "mvs_depth_infer: NULL argument");
+    return depth_infer_impl(feats, proj, depth_values, weights_blob, depth_out, conf_out, workspace,
+                            workspace_bytes, N, C, D, h, w, dtype, stream);
+}
+
+// ---- FeatureNet (models/mvsnet.py:10-30) and the whole MVSNet.forward from images -------------
+
+int mvs_query_feature_blob(size_t* bytes) {
+    if (!bytes) return fail(MVS_ERR_NULL, "bytes is NULL");
+    *bytes = feat_blob_layout().total_floats * sizeof(float);
+    return MVS_OK;
+}
+
+int mvs_pack_feature_weights(const float* const* conv_weights, const float* const* bn_params,
+                             const float* feature_bias, float eps, void* blob_out, size_t blob_bytes) {
+    if (!conv_weights || !bn_params || !feature_bias || !blob_out)
+        return fail(MVS_ERR_NULL, "mvs_pack_feature_weights: NULL argument");
+    const FeatBlob L = feat_blob_layout();
+    if (blob_bytes < L.total_floats * sizeof(float))
+        return fail(MVS_ERR_WORKSPACE, "feature blob needs %zu bytes, got %zu",
+                    L.total_floats * sizeof(float), blob_bytes);
+    float* blob = static_cast<float*>(blob_out);
+    std::memset(blob, 0, L.total_floats * sizeof(float));
+    for (int l = 0; l < MVS_FEATURE_LAYERS; ++l) {
+        const FeatLayerSpec& S = kFeatLayers[l];
+        if (!conv_weights[l]) return fail(MVS_ERR_NULL, "feature conv weight %d is NULL", l);
+        const size_t per_co = (size_t)S.cin * S.k * S.k;
+        std::vector<float> wf((size_t)S.cout * per_co);
+        for (int co = 0; co < S.cout; ++co) {
+            float scale = 1.0f, shift = feature_bias[co];
+            if (l < 7) {  // eval BatchNorm2d folded: y = (conv - mean) * gamma / sqrt(var + eps) + beta
+                const float* g = bn_params[4 * l + 0];
+                const float* b = bn_params[4 * l + 1];
+                const float* m = bn_params[4 * l + 2];
+                const float* v = bn_params[4 * l + 3];
+                if (!g || !b || !m || !v) return fail(MVS_ERR_NULL, "feature BN parameter of layer %d is NULL", l);
+                scale = g[co] / std::sqrt(v[co] + eps);
+                shift = b[co] - m[co] * scale;
+            }
+            for (size_t i = 0; i < per_co; ++i) wf[co * per_co + i] = conv_weights[l][co * per_co + i] * scale;
+            blob[L.bias_off[l] + co] = shift;
+        }
+        pack_fconv_weights(wf.data(), S.cin, S.cout, S.k, blob + L.panel_off[l]);
+    }
+    return MVS_OK;
+}
+
+static int check_image_dims(int N, int H, int W) {
+    if (N < 1 || N > 65535) return fail(MVS_ERR_BAD_SHAPE, "number of images N=%d outside [1,65535]", N);
+    if (H < 4 || W < 4) return fail(MVS_ERR_BAD_SHAPE, "image H,W = %d,%d must be >= 4", H, W);
+    if ((size_t)N * H * W * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "N*H*W = %zu exceeds 31-bit offsets", (size_t)N * H * W);
+    return MVS_OK;
+}
+
+int mvs_query_feature_workspace(int N, int H, int W, size_t* bytes) {
+    if (!bytes) return fail(MVS_ERR_NULL, "bytes is NULL");
+    if (int st = check_image_dims(N, H, W)) return st;
+    *bytes = feat_workspace_layout(N, H, W).total;
+    return MVS_OK;
+}
+
+int mvs_feature_layer(int layer, const float* x, float* y, const void* feature_blob, int N, int Hi, int Wi,
+                      void* stream) {
+    if (!x || !y || !feature_blob) return fail(MVS_ERR_NULL, "mvs_feature_layer: NULL argument");
+    if (layer < 0 || layer >= MVS_FEATURE_LAYERS) return fail(MVS_ERR_BAD_SHAPE, "feature layer %d outside [0,8)", layer);
+    if (int st = check_image_dims(N, Hi, Wi)) return st;
+    return launch_feature_layer(layer, x, y, static_cast<const float*>(feature_blob), N, Hi, Wi,
+                                static_cast<hipStream_t>(stream));
+}
+
+int mvs_feature_net(const float* imgs, const void* feature_blob, float* feats_out, void* workspace,
+                    size_t workspace_bytes, int N, int H, int W, void* stream) {
+    if (!imgs || !feature_blob || !feats_out || !workspace)
+        return fail(MVS_ERR_NULL, "mvs_feature_net: NULL argument");
+    if (int st = check_image_dims(N, H, W)) return st;
+    const FeatWorkspace F = feat_workspace_layout(N, H, W);
+    if (workspace_bytes < F.total)
+        return fail(MVS_ERR_WORKSPACE, "feature workspace needs >= %zu bytes, got %zu", F.total, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* c8 = reinterpret_cast<float*>(ws + F.c8);
+    if (int st = launch_feature_net_c8(imgs, static_cast<const float*>(feature_blob), c8,
+                                       reinterpret_cast<float*>(ws + F.bufA),
+                                       reinterpret_cast<float*>(ws + F.bufB), N, H, W, s))
+        return st;
+    return launch_c8_to_nchw(c8, feats_out, N, kC, F.h4, F.w4, s);
+}
+
+int mvs_query_forward_workspace(int N, int H, int W, int D, int dtype, size_t* bytes) {
+    if (!bytes) return fail(MVS_ERR_NULL, "bytes is NULL");
+    if (H % 4 || W % 4) return fail(MVS_ERR_BAD_SHAPE, "image H,W = %d,%d must be multiples of 32", H, W);
+    if (int st = check_dims(N, kC, D, H / 4, W / 4, dtype)) return st;
+    if (int st = check_image_dims(N, H, W)) return st;
+    *bytes = workspace_layout(N, kC, D, H / 4, W / 4, dtype).total + feat_workspace_layout(N, H, W).total;
+    return MVS_OK;
+}
+
+int mvs_forward_images(const float* imgs, const float* proj, const float* depth_values,
+                       const void* feature_blob, const void* weights_blob, float* depth_out,
+                       float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                       int D, int dtype, void* stream) {
+    if (!imgs || !proj || !depth_values || !feature_blob || !weights_blob || !depth_out || !conf_out ||
+        !workspace)
+        return fail(MVS_ERR_NULL, "mvs_forward_images: NULL argument");
+    if (H % 4 || W % 4) return fail(MVS_ERR_BAD_SHAPE, "image H,W = %d,%d must be multiples of 32", H, W);
+    const int h = H / 4, w = W / 4;
+    if (int st = check_dims(N, kC, D, h, w, dtype)) return st;
+    if (int st = check_image_dims(N, H, W)) return st;
+    const Workspace Wd = workspace_layout(N, kC, D, h, w, dtype);
+    const FeatWorkspace F = feat_workspace_layout(N, H, W);
+    if (workspace_bytes < Wd.total + F.total)
+        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", Wd.total + F.total, workspace_bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    char* fws = ws + Wd.total;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* feats_t = reinterpret_cast<float*>(ws + Wd.feats_t);
+    float* bufA = reinterpret_cast<float*>(fws + F.bufA);
+    float* bufB = reinterpret_cast<float*>(fws + F.bufB);
+    const bool narrow = feat16_gather() && dtype != MVS_F32;
+    // the last layer writes the path's C8 feature slot directly (fp32), or a scratch copy that is
+    // then narrowed into it for the 16-bit gather
+    float* c8 = narrow ? reinterpret_cast<float*>(fws + F.c8) : feats_t;
+    if (int st = launch_feature_net_c8(imgs, static_cast<const float*>(feature_blob), c8, bufA, bufB, N, H, W, s))
+        return st;
+    if (narrow)
+        if (int st = launch_narrow_features(c8, feats_t, (size_t)N * kC * h * w, dtype, s)) return st;
+    return depth_infer_impl(nullptr, proj, depth_values, weights_blob, depth_out, conf_out, workspace,
+                            Wd.total, N, kC, D, h, w, dtype, stream);
 }
 
 int mvs_homo_warp(const float* src_fea, const float* rt, const float* depth_values, float* out,

@@ -112,6 +112,60 @@ inline Workspace workspace_layout(int N, int C, int D, int h, int w, int dtype) 
     return W;
 }
 
+// ---- FeatureNet (models/mvsnet.py:15-24): conv0..conv6 (ConvBnReLU) + feature (Conv2d + bias) ----
+struct FeatLayerSpec {
+    int cin, cout, k, stride, relu;
+};
+constexpr FeatLayerSpec kFeatLayers[MVS_FEATURE_LAYERS] = {
+    {3, 8, 3, 1, 1},   {8, 8, 3, 1, 1},   {8, 16, 5, 2, 1},  {16, 16, 3, 1, 1},
+    {16, 16, 3, 1, 1}, {16, 32, 5, 2, 1}, {32, 32, 3, 1, 1}, {32, 32, 3, 1, 0}};
+// feature blob: per layer the MFMA B panel [cin/8][cout/16][(k*k+1)/2][64][4] then 16*NT bias floats
+struct FeatBlob {
+    size_t panel_off[MVS_FEATURE_LAYERS], bias_off[MVS_FEATURE_LAYERS], total_floats;
+};
+inline FeatBlob feat_blob_layout() {
+    FeatBlob L{};
+    size_t off = 0;
+    for (int l = 0; l < MVS_FEATURE_LAYERS; ++l) {
+        const FeatLayerSpec& S = kFeatLayers[l];
+        const size_t nch = (S.cin + 7) / 8, nt = (S.cout + 15) / 16, ks = (S.k * S.k + 1) / 2;
+        L.panel_off[l] = off;
+        off += nch * nt * ks * 64 * 4;
+        L.bias_off[l] = off;
+        off += (nt * 16 + 63) / 64 * 64;
+    }
+    L.total_floats = off;
+    return L;
+}
+// FeatureNet scratch: two ping-pong activation buffers (largest activation = 8 channels at full
+// resolution) and a C8-planar output [4][N][H/4][W/4][8]
+struct FeatWorkspace {
+    size_t bufA, bufB, c8, total;
+    int h4, w4;
+};
+inline FeatWorkspace feat_workspace_layout(int N, int H, int W) {
+    FeatWorkspace F{};
+    const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1;
+    F.h4 = (H2 - 1) / 2 + 1;
+    F.w4 = (W2 - 1) / 2 + 1;
+    const size_t full = ((size_t)N * H * W * 8 * 4 + 255) & ~(size_t)255;
+    const size_t half = ((size_t)N * H2 * W2 * 16 * 4 + 255) & ~(size_t)255;
+    const size_t big = full > half ? full : half;
+    F.bufA = 0;
+    F.bufB = big;
+    F.c8 = 2 * big;
+    F.total = 2 * big + (((size_t)N * F.h4 * F.w4 * 32 * 4 + 255) & ~(size_t)255);
+    return F;
+}
+bool feat16_gather();
+int launch_feature_layer(int l, const float* x, float* y, const float* blob, int N, int Hi, int Wi,
+                         hipStream_t s);
+int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8, float* bufA, float* bufB,
+                          int N, int H, int W, hipStream_t s);
+int launch_c8_to_nchw(const float* in, float* out, int N, int C, int h, int w, hipStream_t s);
+int launch_narrow_features(const float* in, void* out, size_t n, int dtype, hipStream_t s);
+void pack_fconv_weights(const float* w, int cin, int cout, int k, float* bp);
+
 // thread-local error text
 int fail(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);

@@ -5,11 +5,12 @@ and return dict (reference models/mvsnet.py:91-239); parameter/buffer names equa
 reference's so `load_state_dict(torch.load(ckpt)['model'])` works, with or without the
 `module.` prefix that `nn.DataParallel` adds (eval.py:309-315).
 
-What runs where
-  FeatureNet (mvsnet.py:10-30)            PyTorch-ROCm, all views of all batch items in one call
-  homography warp, variance volume,       hand-written gfx950 HIP kernels behind the C ABI
-  CostRegNet, softmax / soft-argmin /     (include/mvs_abi.h -> csrc/libmvs_hip.so), enqueued on
-  photometric confidence                  torch's current stream, one mvs_depth_infer per item
+What runs where: everything -- FeatureNet (mvsnet.py:10-30), homography warp, variance volume,
+CostRegNet, softmax / soft-argmin / photometric confidence -- runs in hand-written gfx950 HIP
+kernels behind the C ABI (include/mvs_abi.h -> csrc/libmvs_hip.so), enqueued on torch's current
+stream, one mvs_forward_images per batch item.  `model.feature_impl = "torch"` keeps FeatureNet on
+PyTorch-ROCm (MIOpen) and hands NCHW features to mvs_depth_infer (the round-1 arrangement; kept
+for A/B timing).  The `feature` sub-module is a parameter container either way.
 
 Inference only: forward() raises in training mode, on CPU tensors, or if libmvs_hip.so is
 missing -- there is deliberately no PyTorch fallback for the HIP path.
@@ -95,6 +96,8 @@ class MVSNet(nn.Module):
         # storage dtype of the HIP path's private volumes: "f32" (default, = the reference's fp32
         # pipeline), "f16" or "bf16" (BASELINE.json configs 4 / 2); arithmetic is always fp32
         self.storage_dtype = "f32"
+        # "hip": FeatureNet in libmvs_hip (default); "torch": PyTorch-ROCm convolutions
+        self.feature_impl = "hip"
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
         if self.refine:
@@ -119,9 +122,31 @@ class MVSNet(nn.Module):
         self._workspace_cache = {}
 
     # -- caches ------------------------------------------------------------------------------
-    def _param_versions(self):
-        cr = self.cost_regularization
+    def _param_versions(self, mod=None):
+        cr = self.cost_regularization if mod is None else mod
         return tuple((t.data_ptr(), t._version) for t in list(cr.parameters()) + list(cr.buffers()))
+
+    def _feature_blob(self, device):
+        key = ("feature", device.index if device.index is not None else torch.cuda.current_device())
+        versions = self._param_versions(self.feature)
+        with self._cache_lock:
+            hit = self._blob_cache.get(key)
+            if hit is not None and hit[0] == versions:
+                return hit[1]
+            state = {k: v.detach().cpu() for k, v in self.feature.state_dict().items()}
+            blob = _lib.pack_feature_weights(state, eps=self.feature.conv0.bn.eps).to(device)
+            self._blob_cache[key] = (versions, blob)
+            return blob
+
+    def _forward_workspace(self, device, N, H, W, D, dtype):
+        key = ("fwd", device.index, N, H, W, D, dtype)
+        with self._cache_lock:
+            ws = self._workspace_cache.get(key)
+            if ws is None:
+                ws = torch.empty(_lib.query_forward_workspace(N, H, W, D, dtype), dtype=torch.uint8,
+                                 device=device)
+                self._workspace_cache[key] = ws
+            return ws
 
     def _weights_blob(self, device):
         key = device.index if device.index is not None else torch.cuda.current_device()
@@ -161,6 +186,24 @@ class MVSNet(nn.Module):
         device = imgs.device
         B, N, _, H, W = imgs.shape
         D = depth_values.shape[1]
+        if self.feature_impl not in ("hip", "torch"):
+            raise RuntimeError(f"feature_impl must be 'hip' or 'torch', got {self.feature_impl!r}")
+        if self.feature_impl == "hip":
+            if imgs.shape[2] != 3 or H % 32 or W % 32:
+                raise RuntimeError(f"imgs must be [B,N,3,H,W] with H, W multiples of 32, got {tuple(imgs.shape)}")
+            with torch.cuda.device(device), torch.no_grad():
+                imgs_f = _lib._dev_f32(imgs.to(torch.float32), "imgs")
+                proj = _lib._dev_f32(proj_matrices.to(device), "proj_matrices")
+                dv = _lib._dev_f32(depth_values.to(device), "depth_values")
+                blob, fblob = self._weights_blob(device), self._feature_blob(device)
+                dt = _lib.dtype_code(self.storage_dtype)
+                ws = self._forward_workspace(device, N, H, W, D, dt)
+                depth = torch.empty((B, H // 4, W // 4), dtype=torch.float32, device=device)
+                conf = torch.empty((B, H // 4, W // 4), dtype=torch.float32, device=device)
+                # steps 1-4 (reference mvsnet.py:125-218): one enqueue per batch item, same stream
+                for b in range(B):
+                    _lib.forward_images(imgs_f[b], proj[b], dv[b], fblob, blob, ws, depth[b], conf[b], dtype=dt)
+            return {"depth": depth, "photometric_confidence": conf}
         with torch.cuda.device(device), torch.no_grad():
             # step 1. feature extraction (reference mvsnet.py:125), all B*N images in one call
             feats = self.feature(imgs.reshape(B * N, imgs.shape[2], H, W).to(torch.float32))

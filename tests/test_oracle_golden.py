@@ -82,3 +82,14 @@ def test_nonfinite_coordinates_give_nan():
     out = orc.homo_warp(fea, src, ref, np.array([1.0, 2.0], np.float32))
     assert np.isnan(out[:, 0]).all()
     assert np.isfinite(out[:, 1]).all()
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "b2"])
+def test_feature_net_matches_reference_features(name, weights):
+    """oracle.feature_net vs `model.feature(img)` of the imported reference (mvsnet.py:125)."""
+    fx = load_fixture(name)
+    imgs, feats = fx["imgs"], fx["features"]
+    for b in range(imgs.shape[0]):
+        for v in range(imgs.shape[1]):
+            got = orc.feature_net(imgs[b, v], weights)
+            np.testing.assert_allclose(got, feats[b, v], rtol=1e-4, atol=2e-5)

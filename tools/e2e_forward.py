@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the drop-in MVSNet.forward from images (FeatureNet on PyTorch-ROCm + H2D of
-the images + the HIP depth path); for DESIGN.md -- bench.py's `value` is the path-only figure."""
+"""End-to-end timing of the drop-in MVSNet.forward from images (FeatureNet in HIP or on PyTorch-ROCm,
+with / without H2D of the images, + the HIP depth path); for DESIGN.md -- bench.py's `value` is the path-only figure."""
 import os
 import sys
 import time
@@ -21,7 +21,8 @@ model = model.to(dev).eval()
 imgs, proj, dv = synthetic.make_inputs(N, H, W, D, seed=0, interval_scale=cfg["interval_scale"])
 imgs_h = torch.from_numpy(imgs).pin_memory()
 proj_d, dv_d = torch.from_numpy(proj).to(dev), torch.from_numpy(dv).to(dev)
-for mode in ("resident", "h2d"):
+for impl, mode in (("hip", "resident"), ("hip", "h2d"), ("torch", "resident"), ("torch", "h2d")):
+    model.feature_impl = impl
     for _ in range(3):
         model(imgs_h.to(dev), proj_d, dv_d)
     torch.cuda.synchronize()
@@ -34,4 +35,4 @@ for mode in ("resident", "h2d"):
         out = model(imgs_d, proj_d, dv_d)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    print(f"{mode}: {1 / dt:.1f} maps/s ({dt * 1e3:.3f} ms per forward incl. FeatureNet on {N} views)")
+    print(f"FeatureNet={impl} {mode}: {1 / dt:.1f} maps/s ({dt * 1e3:.3f} ms per forward incl. FeatureNet on {N} views)")
