@@ -19,6 +19,8 @@
 //   chunk c+1 overlaps the MFMAs of chunk c with unconditional loads (counted vmcnt).
 // Cout = 8 layers (conv0, conv1) run with a half-empty N-tile: they are HBM-bound at full
 // resolution (2 x 52 MB at 5 x 512 x 640), not MFMA-bound.
+#include <cstdlib>
+
 #include "mvs_internal.h"
 #include "storage.h"
 
@@ -200,6 +202,156 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv0 + conv1 fused (models/mvsnet.py:15-16,27): both run at full resolution with 8 output
+// channels, so as separate kernels they are pure HBM round trips (2 x 52 MB at 5 x 512 x 640).
+// Here a block stages the 12 x 36 RGB halo of its 8 x 32 output tile, evaluates conv0 (27 taps x
+// 8 channels, 216 FMAs per pixel) on the VALU for the 10 x 34 pixels conv1 needs, writes them
+// straight into conv1's LDS A-tile (zero where the pixel lies outside the image: conv1 pads
+// conv0's OUTPUT with zeros), then runs conv1 on the MFMA as fconv_mfma_kernel does.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fconv01_fused_kernel(
+    const float* __restrict__ img,   // [N][3][H][W]
+    const float* __restrict__ w0,    // [27][8] folded conv0 weights, k = (ci*3+ky)*3+kx ; then bias [8]
+    const float* __restrict__ bp,    // conv1 panel [1][1][5][64][4]
+    const float* __restrict__ bias,  // conv1 bias
+    float* __restrict__ y,           // [1][N][H][W][8]
+    int N, int H, int W) {
+    using G = FConv<8, 8, 3, 1, 4, 4>;
+    constexpr int IY = G::HY + 2, IX = G::HX + 2, IXP = IX + 1;  // 12 x 36 image halo, row pitch 37
+    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
+    __shared__ float itile[3 * IY * IXP];
+    __shared__ __attribute__((aligned(16))) float w0s[28 * 8];  // conv0 weights + bias (broadcast reads)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (W + 31) / 32;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, n = blockIdx.y;
+    const int ox0 = bx * 32, oy0 = by * 8;
+    const size_t HW = (size_t)H * W;
+    const float* im = img + (size_t)n * 3 * HW;
+
+    f32x4 breg[G::KS];
+    {
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) + lane;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) breg[ks] = bsrc[ks * 64];
+    }
+    if (tid < 28 * 8) w0s[tid] = w0[tid];
+    // phase 1: RGB halo (origin = output origin - 2)
+    for (int i = tid; i < 3 * IY * IX; i += 256) {
+        const int c = i / (IY * IX), rem = i - c * (IY * IX);
+        const int iy = rem / IX, ix = rem - iy * IX;
+        const int gy = oy0 - 2 + iy, gx = ox0 - 2 + ix;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = im[c * HW + (size_t)gy * W + gx];
+        itile[(c * IY + iy) * IXP + ix] = v;
+    }
+    __syncthreads();
+    // phase 2: conv0 + BN + ReLU on the VALU for the 10 x 34 pixels of conv1's halo; a thread owns
+    // pixels tid and tid + 256 so that each (uniform, scalar-loaded) weight feeds two pixels
+    {
+        const int v0 = tid, v1 = (tid + 256 < G::NVOX) ? tid + 256 : tid;
+        const int hy0 = v0 / G::HX, hx0 = v0 - hy0 * G::HX;
+        const int hy1 = v1 / G::HX, hx1 = v1 - hy1 * G::HX;
+        const float* p0 = itile + hy0 * IXP + hx0;
+        const float* p1 = itile + hy1 * IXP + hx1;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 a0[4], a1[4];  // channel pairs: v_pk_fma_f32 does two FMAs per lane per issue
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] = a1[j] = (f32x2){w0s[27 * 8 + 2 * j], w0s[27 * 8 + 2 * j + 1]};
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c)
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float q0 = p0[(c * IY + ky) * IXP + kx];
+                    const float q1 = p1[(c * IY + ky) * IXP + kx];
+                    const f32x2* wv = reinterpret_cast<const f32x2*>(w0s + ((c * 3 + ky) * 3 + kx) * 8);
+                    const f32x2 q0v = (f32x2){q0, q0}, q1v = (f32x2){q1, q1};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2 w2 = wv[j];
+                        a0[j] = __builtin_elementwise_fma(q0v, w2, a0[j]);
+                        a1[j] = __builtin_elementwise_fma(q1v, w2, a1[j]);
+                    }
+                }
+        const bool in0 = (oy0 - 1 + hy0) >= 0 && (oy0 - 1 + hy0) < H && (ox0 - 1 + hx0) >= 0 && (ox0 - 1 + hx0) < W;
+        const bool in1 = (oy0 - 1 + hy1) >= 0 && (oy0 - 1 + hy1) < H && (ox0 - 1 + hx1) >= 0 && (ox0 - 1 + hx1) < W;
+        f32x4 lo, hi;
+        lo.x = in0 ? fmaxf(a0[0][0], 0.f) : 0.f; lo.y = in0 ? fmaxf(a0[0][1], 0.f) : 0.f;
+        lo.z = in0 ? fmaxf(a0[1][0], 0.f) : 0.f; lo.w = in0 ? fmaxf(a0[1][1], 0.f) : 0.f;
+        hi.x = in0 ? fmaxf(a0[2][0], 0.f) : 0.f; hi.y = in0 ? fmaxf(a0[2][1], 0.f) : 0.f;
+        hi.z = in0 ? fmaxf(a0[3][0], 0.f) : 0.f; hi.w = in0 ? fmaxf(a0[3][1], 0.f) : 0.f;
+        float* dst = tile + (hy0 * G::HXP + hx0) * G::VS;
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        *reinterpret_cast<f32x4*>(dst + 4) = hi;
+        if (tid + 256 < G::NVOX) {
+            lo.x = in1 ? fmaxf(a1[0][0], 0.f) : 0.f; lo.y = in1 ? fmaxf(a1[0][1], 0.f) : 0.f;
+            lo.z = in1 ? fmaxf(a1[1][0], 0.f) : 0.f; lo.w = in1 ? fmaxf(a1[1][1], 0.f) : 0.f;
+            hi.x = in1 ? fmaxf(a1[2][0], 0.f) : 0.f; hi.y = in1 ? fmaxf(a1[2][1], 0.f) : 0.f;
+            hi.z = in1 ? fmaxf(a1[3][0], 0.f) : 0.f; hi.w = in1 ? fmaxf(a1[3][1], 0.f) : 0.f;
+            dst = tile + (hy1 * G::HXP + hx1) * G::VS;
+            *reinterpret_cast<f32x4*>(dst) = lo;
+            *reinterpret_cast<f32x4*>(dst + 4) = hi;
+        }
+    }
+    __syncthreads();
+    // phase 3: conv1 on the MFMA (NT = 1, 4 M-groups of 4 M-tiles)
+    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
+    const int ry = r >> 3, rx = r & 7;
+    f32x4 acc[G::MPW];
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = wave * G::MPW + i;
+        const int tx = t % 4, ty = t / 4;
+        abase[i] = ((2 * ty + ry) * G::HXP + (8 * tx + rx)) * G::VS + (g & 1) * 4;
+        acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        const int koff = gh ? G::tap_off(2 * ks + 1) : G::tap_off(2 * ks);
+        f32x4 a[G::MPW];
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) a[i] = *reinterpret_cast<const f32x4*>(tile + abase[i] + koff);
+        const f32x4 bq = breg[ks];
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
+    }
+    const int col = lane & 15;
+    if (col >= 8) return;
+    const float bv = bias[col];
+    float* yplane = y + (size_t)n * HW * 8 + col;
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = wave * G::MPW + i;
+        const int tx = t % 4, ty = t / 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
+            if (gy < H && gx < W) yplane[((size_t)gy * W + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+        }
+    }
+}
+
+int launch_feature_conv01(const float* imgs, float* y, const float* blob, int N, int H, int W, hipStream_t s) {
+    const FeatBlob L = feat_blob_layout();
+    if ((size_t)N * H * W * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "feature_net: activation plane exceeds 31-bit offsets");
+    dim3 grid(((W + 31) / 32) * ((H + 7) / 8), N);
+    fconv01_fused_kernel<<<grid, 256, 0, s>>>(imgs, blob + L.l0_direct_off, blob + L.panel_off[1],
+                                               blob + L.bias_off[1], y, N, H, W);
+    return check_hip(hipGetLastError(), "fconv01_fused launch");
+}
+
 template <int CIN, int COUT, int KW, int S, int BY, int BX, bool RELU, bool IMG_IN>
 static int run_fconv(const float* x, float* y, const float* bp, const float* bias, int N, int Hi, int Wi,
                      hipStream_t s) {
@@ -237,8 +389,16 @@ int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8,
                           int N, int H, int W, hipStream_t s) {
     const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1, H4 = (H2 - 1) / 2 + 1, W4 = (W2 - 1) / 2 + 1;
     int st;
-    if ((st = launch_feature_layer(0, imgs, bufA, blob, N, H, W, s))) return st;
-    if ((st = launch_feature_layer(1, bufA, bufB, blob, N, H, W, s))) return st;
+    static const bool split01 = [] {   // MVS_FEAT_SPLIT01=1: conv0 and conv1 as separate kernels
+        const char* e = getenv("MVS_FEAT_SPLIT01");
+        return e && e[0] == '1';
+    }();
+    if (split01) {
+        if ((st = launch_feature_layer(0, imgs, bufA, blob, N, H, W, s))) return st;
+        if ((st = launch_feature_layer(1, bufA, bufB, blob, N, H, W, s))) return st;
+    } else if ((st = launch_feature_conv01(imgs, bufB, blob, N, H, W, s))) {
+        return st;
+    }
     if ((st = launch_feature_layer(2, bufB, bufA, blob, N, H, W, s))) return st;
     if ((st = launch_feature_layer(3, bufA, bufB, blob, N, H2, W2, s))) return st;
     if ((st = launch_feature_layer(4, bufB, bufA, blob, N, H2, W2, s))) return st;

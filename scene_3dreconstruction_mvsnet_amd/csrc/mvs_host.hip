@@ -348,6 +348,13 @@ int mvs_pack_feature_weights(const float* const* conv_weights, const float* cons
             blob[L.bias_off[l] + co] = shift;
         }
         pack_fconv_weights(wf.data(), S.cin, S.cout, S.k, blob + L.panel_off[l]);
+        if (l == 0) {  // plain copy for the VALU half of the fused conv0+conv1 kernel
+            float* d = blob + L.l0_direct_off;
+            for (int co = 0; co < 8; ++co) {
+                for (int k = 0; k < 27; ++k) d[k * 8 + co] = wf[co * 27 + k];
+                d[27 * 8 + co] = blob[L.bias_off[0] + co];
+            }
+        }
     }
     return MVS_OK;
 }

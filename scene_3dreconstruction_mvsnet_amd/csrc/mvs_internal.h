@@ -121,7 +121,9 @@ constexpr FeatLayerSpec kFeatLayers[MVS_FEATURE_LAYERS] = {
     {16, 16, 3, 1, 1}, {16, 32, 5, 2, 1}, {32, 32, 3, 1, 1}, {32, 32, 3, 1, 0}};
 // feature blob: per layer the MFMA B panel [cin/8][cout/16][(k*k+1)/2][64][4] then 16*NT bias floats
 struct FeatBlob {
-    size_t panel_off[MVS_FEATURE_LAYERS], bias_off[MVS_FEATURE_LAYERS], total_floats;
+    size_t panel_off[MVS_FEATURE_LAYERS], bias_off[MVS_FEATURE_LAYERS];
+    size_t l0_direct_off;  // conv0 for the fused conv0+conv1 kernel: [27][8] weights (k = (ci*3+ky)*3+kx), bias [8]
+    size_t total_floats;
 };
 inline FeatBlob feat_blob_layout() {
     FeatBlob L{};
@@ -134,6 +136,8 @@ inline FeatBlob feat_blob_layout() {
         L.bias_off[l] = off;
         off += (nt * 16 + 63) / 64 * 64;
     }
+    L.l0_direct_off = off;
+    off += 256;
     L.total_floats = off;
     return L;
 }
