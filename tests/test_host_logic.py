@@ -194,3 +194,59 @@ def test_module_survives_deepcopy_and_pickle():
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert isinstance(m3, MVSNet) and m3._workspace_cache == {}
+
+
+def test_pack_feature_weights_folds_bn_and_relayouts():
+    """FeatureNet blob: per layer the MFMA panel [cin/8][cout/16][(k*k+1)/2][64][4] of the BN-folded
+    weights, then the folded bias; conv0 additionally as a plain [27][8] table (fused kernel)."""
+    w = load_weights()
+    st = {k[len("feature."):]: v for k, v in w.items() if k.startswith("feature.")}
+    blob = _lib.pack_feature_weights(st).numpy().view(np.float32)
+    off = 0
+    folded0 = None
+    for l, (ci, co, k, _) in enumerate(_lib.FEATURE_LAYERS):
+        wt = st[_lib.FEATURE_WEIGHT_KEYS[l]].astype(np.float64)
+        if l < 7:
+            scale = st[f"conv{l}.bn.weight"] / np.sqrt(st[f"conv{l}.bn.running_var"].astype(np.float64) + 1e-5)
+            shift = st[f"conv{l}.bn.bias"] - st[f"conv{l}.bn.running_mean"] * scale
+        else:
+            scale, shift = np.ones(co), st["feature.bias"].astype(np.float64)
+        wf = wt * scale[:, None, None, None]
+        if l == 0:
+            folded0 = (wf, shift)
+        nch, nt, ks = (ci + 7) // 8, (co + 15) // 16, (k * k + 1) // 2
+        panel = blob[off:off + nch * nt * ks * 256].reshape(nch, nt, ks, 64, 4)
+        rng = np.random.default_rng(l)
+        for _ in range(40):
+            c, t, s, lane, j4 = rng.integers(nch), rng.integers(nt), rng.integers(ks), rng.integers(64), rng.integers(4)
+            g, n = lane >> 4, lane & 15
+            tap, cin_i, cout_i = 2 * s + (g >> 1), 8 * c + 4 * (g & 1) + j4, 16 * t + n
+            want = wf[cout_i, cin_i, tap // k, tap % k] if (tap < k * k and cin_i < ci and cout_i < co) else 0.0
+            np.testing.assert_allclose(panel[c, t, s, lane, j4], want, rtol=2e-6, atol=1e-8)
+        off += nch * nt * ks * 256
+        np.testing.assert_allclose(blob[off:off + co], shift, rtol=2e-6, atol=1e-7)
+        off += (nt * 16 + 63) // 64 * 64
+    direct = blob[off:off + 28 * 8].reshape(28, 8)
+    np.testing.assert_allclose(direct[:27], folded0[0].reshape(8, 27).T, rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(direct[27], folded0[1], rtol=2e-6, atol=1e-7)
+    assert (off + 256) * 4 == _lib.query_feature_blob()
+    bad = dict(st)
+    bad["conv2.conv.weight"] = bad["conv2.conv.weight"][:, :, :3, :3]
+    with pytest.raises(RuntimeError):
+        _lib.pack_feature_weights(bad)
+
+
+def test_feature_and_forward_workspace_queries():
+    full = 5 * 512 * 640 * 8 * 4
+    assert _lib.query_feature_workspace(5, 512, 640) == 2 * full + 5 * 32 * 128 * 160 * 4
+    assert _lib.query_forward_workspace(5, 512, 640, 192) == \
+        _lib.query_workspace(5, 32, 192, 128, 160) + _lib.query_feature_workspace(5, 512, 640)
+    for bad in [(5, 510, 640, 192), (5, 512, 640, 190), (0, 512, 640, 192)]:
+        with pytest.raises(_lib.MvsError) as e:
+            _lib.query_forward_workspace(*bad)
+        assert e.value.code == 1
+    with pytest.raises(_lib.MvsError):
+        _lib.query_feature_workspace(1, 2, 2)
+    lib = _lib.load()
+    assert lib.mvs_forward_images(None, None, None, None, None, None, None, None, 0, 5, 512, 640, 192, 0, None) == 5
+    assert lib.mvs_feature_net(None, None, None, None, 0, 5, 512, 640, None) == 5
