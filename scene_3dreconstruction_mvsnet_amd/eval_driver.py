@@ -7,8 +7,9 @@ Per sample it runs the drop-in MVSNet forward and writes, under `outdir`:
     {scan}/cams/{view:08d}_cam.txt      <- write_cam(K, E, ["000","2.5","",""]) (eval.py:396,107-126)
     {scan}/images/{view:08d}.png        <- uint8(ref image * 255), RGB          (eval.py:346-350)
 with `filename = "{scan}/{{}}/{view:08d}{{}}"` as the reference datasets produce it
-(datasets/dataloader_eval.py:176).  Not reproduced (flagged, not silently changed): the PNG previews
-(eval.py:388,393, need cv2), the point-cloud accumulation (eval.py:409-440, needs open3d).
+(datasets/dataloader_eval.py:176).  The grey PNG previews next to the PFMs (eval.py:388,393) are written with PIL (cv2 is absent; same
+pixel values as cv2.imwrite would store).  Not reproduced (flagged, not silently changed): the
+point-cloud accumulation of the debug view (eval.py:409-440, needs open3d).
 
 Sharding replaces `nn.DataParallel` (eval.py:309): rank r of R processes dataset items r::R
 (scene_3dreconstruction_mvsnet_amd.sharding); every rank writes its own files, so no collective is
@@ -61,6 +62,14 @@ def _write_sample(job) -> None:
         Image.fromarray(np.uint8(np.transpose(img, (1, 2, 0)) * 255)).save(img_fn, compress_level=1)
     data_io.save_pfm(depth_fn, depth)
     data_io.save_pfm(conf_fn, conf)
+    # grey previews next to the PFMs (eval.py:388,393).  The reference writes them with cv2.imwrite:
+    # depth as uint8(min-max normalised * 255); the confidence array is handed over as float32, which
+    # OpenCV converts with saturate_cast<uchar> (round-half-even), i.e. to 0 / 1
+    with np.errstate(all="ignore"):
+        span = np.max(depth) - np.min(depth)
+        prev = np.uint8((depth - np.min(depth)) / span * 255) if span > 0 else np.zeros(depth.shape, np.uint8)
+    Image.fromarray(prev).save(depth_fn.replace(".pfm", ".png"), compress_level=1)
+    Image.fromarray(np.uint8(np.clip(np.rint(conf), 0, 255))).save(conf_fn.replace(".pfm", ".png"), compress_level=1)
     if K is not None and E is not None:
         write_cam(cam_fn, K=K, R=E, depth_params=["000", "2.5", "", ""])
     _tick("writer.files", t0)

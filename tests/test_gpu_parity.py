@@ -494,6 +494,14 @@ def test_save_depth_sharded_writes_reference_file_tree(tmp_path):
         np.testing.assert_array_equal(d, out["depth"][0].cpu().numpy())
         np.testing.assert_array_equal(c, out["photometric_confidence"][0].cpu().numpy())
         assert (tmp_path / "scan9" / "cams" / f"{i:08d}_cam.txt").read_text().startswith("extrinsic\n1.0 0.0 ")
+        # reference image (eval.py:346-350) and the grey previews (eval.py:388,393)
+        from PIL import Image
+        img = np.array(Image.open(str(tmp_path / "scan9" / "images" / f"{i:08d}.png")))
+        np.testing.assert_array_equal(img, np.uint8(np.transpose(s["imgs"][0], (1, 2, 0)) * 255))
+        prev = np.array(Image.open(str(tmp_path / "scan9" / "depth_est" / f"{i:08d}.png")))
+        np.testing.assert_array_equal(prev, np.uint8((d - d.min()) / (d.max() - d.min()) * 255))
+        cprev = np.array(Image.open(str(tmp_path / "scan9" / "confidence" / f"{i:08d}.png")))
+        assert cprev.shape == c.shape and set(np.unique(cprev)) <= {0, 1}
 
 
 # ------------------------------------------------------------------------------ randomized shapes
