@@ -310,6 +310,12 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
         return e && e[0] == '1';
     }();
     if (use_lds && N <= 64 && dtype == MVS_F32) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
+    // Tap-cache kernel (warp_variance_tc.hip) for 2..5 views; MVS_WARP_TC=0 keeps the plain gather
+    static const bool use_tc = [] {
+        const char* e = getenv("MVS_WARP_TC");
+        return !(e && e[0] == '0');
+    }();
+    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 32 < ((size_t)1 << 31)) return launch_warp_variance_tc(feats_p, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
     float* v = static_cast<float*>(var);

@@ -1,0 +1,194 @@
+// warp_variance_tc.hip -- warp + variance with the bilinear taps cached in registers across depth.
+//
+// Why: the plain kernel (warp_variance.hip) is bound by the CU's 64 B/clk vector-L1 path: 8 GB of
+// taps per cfg2 map.  But for a fixed (pixel, source view) the sampling position moves along the
+// epipolar line by only a fraction of a texel per depth step (DTU-like rigs: 0.03-0.6 px), so the
+// 2x2 texel cell -- hence all four taps -- is the same as at the previous depth ~80 % of the time.
+// Only the bilinear weights change.  This kernel keeps the four taps of every source view in
+// registers while a thread marches through a slab of depths and re-gathers a view's taps only when
+// its cell index changed.  Same arithmetic as the plain kernel (same taps, same weight formula, same
+// fma nesting), so results are bit-identical to it.
+//
+// Mapping: thread = (pixel, plane): 8 channels, 32 B per tap.  The four lanes of a quad own the four
+// planes of one pixel; lane j of the quad evaluates the projection + weights of source view j+1
+// (make_samp, ~60 VALU instructions) and the quad shares the results with DPP quad broadcasts, so
+// the coordinate work per pixel does not grow with the finer thread granularity.
+// Register budget: 32 VGPRs of cached taps per source view -> N-1 <= 4 source views (N <= 5); other
+// view counts use the plain kernel.
+#include <cstdlib>
+
+#include "mvs_internal.h"
+#include "storage.h"
+#include "warp_common.h"
+
+namespace mvs {
+
+namespace {
+
+constexpr int kTcPixPerBlock = 64;
+
+__device__ __forceinline__ float quad_bcast(float v, int lane) {
+    const int i = __float_as_int(v);
+    int r;
+    switch (lane) {  // dpp_ctrl quad_perm(l,l,l,l) must be an immediate
+        case 0: r = __builtin_amdgcn_mov_dpp(i, 0x00, 0xF, 0xF, true); break;
+        case 1: r = __builtin_amdgcn_mov_dpp(i, 0x55, 0xF, 0xF, true); break;
+        case 2: r = __builtin_amdgcn_mov_dpp(i, 0xAA, 0xF, 0xF, true); break;
+        default: r = __builtin_amdgcn_mov_dpp(i, 0xFF, 0xF, 0xF, true); break;
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ int quad_bcast(int v, int lane) {
+    switch (lane) {
+        case 0: return __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true);
+        case 1: return __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true);
+        case 2: return __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true);
+        default: return __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, true);
+    }
+}
+
+// one tap = 8 channels = 32 B at base + byte_off.  Plain loads on purpose: with inline-asm gathers
+// (all views' gathers in flight at once, one manual s_waitcnt) the kernel ran 4 % faster, but hipcc
+// is free to copy asm output registers at control-flow joins -- i.e. to read a register whose load
+// is still in flight -- and did so as soon as the reload logic had more than one path.
+__device__ __forceinline__ void gather_tap(f32x4& lo, f32x4& hi, unsigned byte_off, const float* base) {
+    const char* p = reinterpret_cast<const char*>(base) + byte_off;
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 16);
+}
+
+template <int DT, int NV>
+__global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __restrict__ feats_p,  // [4][N][hw][8]
+                                                               const float* __restrict__ rt,
+                                                               const float* __restrict__ dv,
+                                                               void* __restrict__ var, int N, int D, int h,
+                                                               int w, int slab) {
+    const int pl = threadIdx.x & 3;
+    const int hw = h * w;
+    const int p_raw = blockIdx.x * kTcPixPerBlock + (threadIdx.x >> 2);
+    const bool live = p_raw < hw;
+    const int p = live ? p_raw : hw - 1;  // keep whole quads / waves converged for the DPP exchange
+    const int y = p / w, x = p - y * w;
+    const int d0 = blockIdx.y * slab, d1 = min(d0 + slab, D);
+    // 32-bit element offsets from the uniform base keep the gathers in the saddr + voffset form (one
+    // VGPR per address instead of a 64-bit pair); the launcher guarantees 4*N*hw*8 floats < 2^31 bytes
+    const unsigned plane = (unsigned)pl * (unsigned)N * (unsigned)hw * 8u;  // this thread's channel plane
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)x, fy = (float)y;
+    const float inv_n = 1.0f / (float)N;
+    const size_t V0 = (size_t)D * hw;
+
+    const float4 ref_lo = *reinterpret_cast<const float4*>(feats_p + (plane + (unsigned)p * 8u));
+    const float4 ref_hi = *reinterpret_cast<const float4*>(feats_p + (plane + (unsigned)p * 8u + 4u));
+
+    // the projection this lane evaluates for its quad: source view min(pl, NV-1) + 1
+    const int myv = pl < NV ? pl : NV - 1;
+    const float* r = rt + (size_t)myv * 12;
+    const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+    const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+    const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+    const float tx = r[9], ty = r[10], tz = r[11];
+
+    f32x4 tap[NV][4][2];  // cached taps: [view][00,01,10,11][lo,hi]
+    int key00[NV], key01[NV], key10[NV], key11[NV];  // offsets of the cached taps
+#pragma unroll
+    for (int v = 0; v < NV; ++v) key00[v] = key01[v] = key10[v] = key11[v] = -1;
+
+    // Software pipeline per depth: (1) compare each view's tap offsets with the cached ones and issue
+    // the re-gathers, (2) evaluate the NEXT depth's projection while those loads are in flight,
+    // (3) blend with this depth's weights, accumulate, store.
+    Samp mine = make_samp(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w, 0, 0, w, h);
+    for (int d = d0; d < d1; ++d) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int o00 = quad_bcast(mine.o00, v), o11 = quad_bcast(mine.o11, v);
+            // o00 = ya*w + xa and o11 = yb*w + xb pin down all four (clamped) tap offsets
+            if (o00 != key00[v] || o11 != key11[v]) {
+                const int o01 = quad_bcast(mine.o01, v), o10 = quad_bcast(mine.o10, v);
+                const unsigned vb = (plane + (unsigned)(v + 1) * (unsigned)hw * 8u) * 4u;  // bytes
+                // the usual move is one texel along x: the new left column is the old right column
+                // (or vice versa) -- shift the cached taps and gather only the two new ones
+                const bool left = (o00 == key01[v]) && (o10 == key11[v]);   // cell moved +1 in x
+                const bool right = (o01 == key00[v]) && (o11 == key10[v]);   // cell moved -1 in x
+                if (left) {
+                    tap[v][0][0] = tap[v][1][0]; tap[v][0][1] = tap[v][1][1];
+                    tap[v][2][0] = tap[v][3][0]; tap[v][2][1] = tap[v][3][1];
+                    gather_tap(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 32u, feats_p);
+                    gather_tap(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 32u, feats_p);
+                } else if (right) {
+                    tap[v][1][0] = tap[v][0][0]; tap[v][1][1] = tap[v][0][1];
+                    tap[v][3][0] = tap[v][2][0]; tap[v][3][1] = tap[v][2][1];
+                    gather_tap(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 32u, feats_p);
+                    gather_tap(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 32u, feats_p);
+                } else {
+                    gather_tap(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 32u, feats_p);
+                    gather_tap(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 32u, feats_p);
+                    gather_tap(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 32u, feats_p);
+                    gather_tap(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 32u, feats_p);
+                }
+                key00[v] = o00;
+                key01[v] = o01;
+                key10[v] = o10;
+                key11[v] = o11;
+            }
+        }
+        const Samp next = make_samp(qx, qy, qz, tx, ty, tz, dv[min(d + 1, D - 1)], sx, sy, h, w, 0, 0, w, h);
+        float4 S_lo = ref_lo, S_hi = ref_hi;
+        float4 Q_lo = make_float4(ref_lo.x * ref_lo.x, ref_lo.y * ref_lo.y, ref_lo.z * ref_lo.z, ref_lo.w * ref_lo.w);
+        float4 Q_hi = make_float4(ref_hi.x * ref_hi.x, ref_hi.y * ref_hi.y, ref_hi.z * ref_hi.z, ref_hi.w * ref_hi.w);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float w00 = quad_bcast(mine.w00, v), w01 = quad_bcast(mine.w01, v);
+            const float w10 = quad_bcast(mine.w10, v), w11 = quad_bcast(mine.w11, v);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 a = tap[v][0][hh], b = tap[v][1][hh], c = tap[v][2][hh], e = tap[v][3][hh];
+                float4 wv;
+                wv.x = fmaf(a.x, w00, fmaf(b.x, w01, fmaf(c.x, w10, e.x * w11)));
+                wv.y = fmaf(a.y, w00, fmaf(b.y, w01, fmaf(c.y, w10, e.y * w11)));
+                wv.z = fmaf(a.z, w00, fmaf(b.z, w01, fmaf(c.z, w10, e.z * w11)));
+                wv.w = fmaf(a.w, w00, fmaf(b.w, w01, fmaf(c.w, w10, e.w * w11)));
+                if (hh == 0) accum(S_lo, Q_lo, wv);
+                else accum(S_hi, Q_hi, wv);
+            }
+        }
+        if (live) {
+            const float4 o_lo = variance4(S_lo, Q_lo, inv_n), o_hi = variance4(S_hi, Q_hi, inv_n);
+            const size_t o = ((size_t)pl * V0 + (size_t)d * hw + p) * 8;
+            St<DT>::store4(var, o, (f32x4){o_lo.x, o_lo.y, o_lo.z, o_lo.w});
+            St<DT>::store4(var, o + 4, (f32x4){o_hi.x, o_hi.y, o_hi.z, o_hi.w});
+        }
+        mine = next;
+    }
+}
+
+template <int DT>
+int launch_tc_dt(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
+                 int slab, hipStream_t s) {
+    const dim3 grid((h * w + kTcPixPerBlock - 1) / kTcPixPerBlock, (D + slab - 1) / slab);
+    if ((size_t)4 * N * h * w * 8 * sizeof(float) >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "warp_variance_tc: feature copy exceeds 31-bit offsets");
+    switch (N - 1) {
+        case 1: warp_variance_tc_kernel<DT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 2: warp_variance_tc_kernel<DT, 2><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 3: warp_variance_tc_kernel<DT, 3><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 4: warp_variance_tc_kernel<DT, 4><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        default: return fail(MVS_ERR_BAD_SHAPE, "warp_variance_tc: N = %d outside [2,5]", N);
+    }
+    return check_hip(hipGetLastError(), "warp_variance_tc launch");
+}
+
+}  // namespace
+
+// fp32 features [4][N][h][w][8]; 2 <= N <= 5
+int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
+                            int h, int w, int dtype, hipStream_t s) {
+    static const int slab = [] {
+        const char* e = getenv("MVS_WARP_TC_SLAB");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 24;
+    }();
+    MVS_DISPATCH_DTYPE(dtype, (launch_tc_dt<DT>(feats_p, rt, dv, var, N, D, h, w, slab, s)))
+}
+
+}  // namespace mvs
