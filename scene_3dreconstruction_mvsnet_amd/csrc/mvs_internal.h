@@ -183,6 +183,8 @@ int launch_warp_variance(const float* feats_t, const float* rt, const float* dv,
                          int D, int h, int w, int dtype, hipStream_t s);
 int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
                             int h, int w, int dtype, hipStream_t s);
+int launch_warp_variance_tc16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
+                              int h, int w, int dtype, hipStream_t s);
 int launch_warp_variance_lds(const float* feats_p, const float* rt, const float* dv, void* var, int N,
                              int D, int h, int w, hipStream_t s);
 int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bp,

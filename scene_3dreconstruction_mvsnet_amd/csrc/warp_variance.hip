@@ -284,6 +284,15 @@ __global__ __launch_bounds__(256) void warp_variance16_kernel(const void* __rest
 int launch_warp_variance16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                            int h, int w, int dtype, hipStream_t s) {
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
+    // The tap-cache kernel is opt-in here (MVS_WARP_TC16=1): with 16-bit features a tap is one 16-byte
+    // load already, and the plain kernel below is the faster one at cfg5 (0.21 vs 0.25 ms) and cfg3
+    // (1.9 vs 3.2 ms: larger images move further per depth step and lose the depth-fastest L2 order).
+    static const bool use_tc = [] {
+        const char* e = getenv("MVS_WARP_TC16");
+        return e && e[0] == '1';
+    }();
+    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 8 < ((size_t)1 << 31))
+        return launch_warp_variance_tc16(feats16, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
     const bool depth_fastest = (size_t)N * h * w * 64 > ((size_t)24 << 20);
@@ -315,7 +324,7 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
         const char* e = getenv("MVS_WARP_TC");
         return !(e && e[0] == '0');
     }();
-    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 32 < ((size_t)1 << 31)) return launch_warp_variance_tc(feats_p, rt, dv, var, N, D, h, w, dtype, s);
+    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 8 < ((size_t)1 << 31)) return launch_warp_variance_tc(feats_p, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
     float* v = static_cast<float*>(var);

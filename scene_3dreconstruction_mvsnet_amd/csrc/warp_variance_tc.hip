@@ -47,18 +47,27 @@ __device__ __forceinline__ int quad_bcast(int v, int lane) {
     }
 }
 
-// one tap = 8 channels = 32 B at base + byte_off.  Plain loads on purpose: with inline-asm gathers
-// (all views' gathers in flight at once, one manual s_waitcnt) the kernel ran 4 % faster, but hipcc
-// is free to copy asm output registers at control-flow joins -- i.e. to read a register whose load
-// is still in flight -- and did so as soon as the reload logic had more than one path.
-__device__ __forceinline__ void gather_tap(f32x4& lo, f32x4& hi, unsigned byte_off, const float* base) {
-    const char* p = reinterpret_cast<const char*>(base) + byte_off;
-    lo = *reinterpret_cast<const f32x4*>(p);
-    hi = *reinterpret_cast<const f32x4*>(p + 16);
+// one tap = the 8 channels of one C8 plane at element offset `off` of the feature copy (fp32: 32 B,
+// 16-bit features: 16 B, widened to fp32 once when gathered).  Plain loads on purpose: with
+// inline-asm gathers (all views' gathers in flight at once, one manual s_waitcnt) the kernel ran 4 %
+// faster, but hipcc is free to copy asm output registers at control-flow joins -- i.e. to read a
+// register whose load is still in flight -- and did so as soon as the reload logic had two paths.
+template <int FDT>
+__device__ __forceinline__ void gather_tap(f32x4& lo, f32x4& hi, unsigned off, const void* base) {
+    if constexpr (FDT == MVS_F32) {
+        const float* p = static_cast<const float*>(base) + off;
+        lo = *reinterpret_cast<const f32x4*>(p);
+        hi = *reinterpret_cast<const f32x4*>(p + 4);
+    } else {
+        float v[8];
+        load8_16<FDT>(base, off, v);
+        lo = (f32x4){v[0], v[1], v[2], v[3]};
+        hi = (f32x4){v[4], v[5], v[6], v[7]};
+    }
 }
 
-template <int DT, int NV>
-__global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __restrict__ feats_p,  // [4][N][hw][8]
+template <int DT, int FDT, int NV>
+__global__ __launch_bounds__(256) void warp_variance_tc_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
                                                                const float* __restrict__ rt,
                                                                const float* __restrict__ dv,
                                                                void* __restrict__ var, int N, int D, int h,
@@ -78,8 +87,10 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __re
     const float inv_n = 1.0f / (float)N;
     const size_t V0 = (size_t)D * hw;
 
-    const float4 ref_lo = *reinterpret_cast<const float4*>(feats_p + (plane + (unsigned)p * 8u));
-    const float4 ref_hi = *reinterpret_cast<const float4*>(feats_p + (plane + (unsigned)p * 8u + 4u));
+    f32x4 r_lo, r_hi;
+    gather_tap<FDT>(r_lo, r_hi, plane + (unsigned)p * 8u, feats_p);
+    const float4 ref_lo = make_float4(r_lo.x, r_lo.y, r_lo.z, r_lo.w);
+    const float4 ref_hi = make_float4(r_hi.x, r_hi.y, r_hi.z, r_hi.w);
 
     // the projection this lane evaluates for its quad: source view min(pl, NV-1) + 1
     const int myv = pl < NV ? pl : NV - 1;
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __re
             // o00 = ya*w + xa and o11 = yb*w + xb pin down all four (clamped) tap offsets
             if (o00 != key00[v] || o11 != key11[v]) {
                 const int o01 = quad_bcast(mine.o01, v), o10 = quad_bcast(mine.o10, v);
-                const unsigned vb = (plane + (unsigned)(v + 1) * (unsigned)hw * 8u) * 4u;  // bytes
+                const unsigned vb = plane + (unsigned)(v + 1) * (unsigned)hw * 8u;  // elements
                 // the usual move is one texel along x: the new left column is the old right column
                 // (or vice versa) -- shift the cached taps and gather only the two new ones
                 const bool left = (o00 == key01[v]) && (o10 == key11[v]);   // cell moved +1 in x
@@ -113,18 +124,18 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __re
                 if (left) {
                     tap[v][0][0] = tap[v][1][0]; tap[v][0][1] = tap[v][1][1];
                     tap[v][2][0] = tap[v][3][0]; tap[v][2][1] = tap[v][3][1];
-                    gather_tap(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 32u, feats_p);
-                    gather_tap(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 32u, feats_p);
+                    gather_tap<FDT>(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 8u, feats_p);
+                    gather_tap<FDT>(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 8u, feats_p);
                 } else if (right) {
                     tap[v][1][0] = tap[v][0][0]; tap[v][1][1] = tap[v][0][1];
                     tap[v][3][0] = tap[v][2][0]; tap[v][3][1] = tap[v][2][1];
-                    gather_tap(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 32u, feats_p);
-                    gather_tap(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 32u, feats_p);
+                    gather_tap<FDT>(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 8u, feats_p);
+                    gather_tap<FDT>(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 8u, feats_p);
                 } else {
-                    gather_tap(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 32u, feats_p);
-                    gather_tap(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 32u, feats_p);
-                    gather_tap(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 32u, feats_p);
-                    gather_tap(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 32u, feats_p);
+                    gather_tap<FDT>(tap[v][0][0], tap[v][0][1], vb + (unsigned)o00 * 8u, feats_p);
+                    gather_tap<FDT>(tap[v][1][0], tap[v][1][1], vb + (unsigned)o01 * 8u, feats_p);
+                    gather_tap<FDT>(tap[v][2][0], tap[v][2][1], vb + (unsigned)o10 * 8u, feats_p);
+                    gather_tap<FDT>(tap[v][3][0], tap[v][3][1], vb + (unsigned)o11 * 8u, feats_p);
                 }
                 key00[v] = o00;
                 key01[v] = o01;
@@ -162,33 +173,54 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const float* __re
     }
 }
 
-template <int DT>
-int launch_tc_dt(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
+template <int DT, int FDT>
+int launch_tc_dt(const void* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
                  int slab, hipStream_t s) {
     const dim3 grid((h * w + kTcPixPerBlock - 1) / kTcPixPerBlock, (D + slab - 1) / slab);
-    if ((size_t)4 * N * h * w * 8 * sizeof(float) >= ((size_t)1 << 31))
+    if ((size_t)4 * N * h * w * 8 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "warp_variance_tc: feature copy exceeds 31-bit offsets");
     switch (N - 1) {
-        case 1: warp_variance_tc_kernel<DT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
-        case 2: warp_variance_tc_kernel<DT, 2><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
-        case 3: warp_variance_tc_kernel<DT, 3><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
-        case 4: warp_variance_tc_kernel<DT, 4><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 1: warp_variance_tc_kernel<DT, FDT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 2: warp_variance_tc_kernel<DT, FDT, 2><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 3: warp_variance_tc_kernel<DT, FDT, 3><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
+        case 4: warp_variance_tc_kernel<DT, FDT, 4><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); break;
         default: return fail(MVS_ERR_BAD_SHAPE, "warp_variance_tc: N = %d outside [2,5]", N);
     }
     return check_hip(hipGetLastError(), "warp_variance_tc launch");
 }
 
-}  // namespace
-
-// fp32 features [4][N][h][w][8]; 2 <= N <= 5
-int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
-                            int h, int w, int dtype, hipStream_t s) {
+int tc_slab() {
     static const int slab = [] {
         const char* e = getenv("MVS_WARP_TC_SLAB");
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 24;
     }();
-    MVS_DISPATCH_DTYPE(dtype, (launch_tc_dt<DT>(feats_p, rt, dv, var, N, D, h, w, slab, s)))
+    return slab;
+}
+
+}  // namespace
+
+// fp32 features [4][N][h][w][8], volume in `dtype`; 2 <= N <= 5
+int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
+                            int h, int w, int dtype, hipStream_t s) {
+    const int slab = tc_slab();
+    switch (dtype) {
+        case MVS_F32: return launch_tc_dt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
+        case MVS_F16: return launch_tc_dt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
+        case MVS_BF16: return launch_tc_dt<MVS_BF16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
+        default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc: unknown dtype %d", dtype);
+    }
+}
+
+// 16-bit features (same dtype as the volume): half the gather bytes
+int launch_warp_variance_tc16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
+                              int h, int w, int dtype, hipStream_t s) {
+    const int slab = tc_slab();
+    switch (dtype) {
+        case MVS_F16: return launch_tc_dt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, s);
+        case MVS_BF16: return launch_tc_dt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, s);
+        default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc16 needs fp16 or bf16 (dtype %d)", dtype);
+    }
 }
 
 }  // namespace mvs
