@@ -25,6 +25,7 @@ namespace mvs {
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kTcPixPerBlock = 64;
 
 __device__ __forceinline__ float quad_bcast(float v, int lane) {
@@ -89,8 +90,7 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const void* __res
 
     f32x4 r_lo, r_hi;
     gather_tap<FDT>(r_lo, r_hi, plane + (unsigned)p * 8u, feats_p);
-    const float4 ref_lo = make_float4(r_lo.x, r_lo.y, r_lo.z, r_lo.w);
-    const float4 ref_hi = make_float4(r_hi.x, r_hi.y, r_hi.z, r_hi.w);
+    const f32x2 refp[4] = {{r_lo.x, r_lo.y}, {r_lo.z, r_lo.w}, {r_hi.x, r_hi.y}, {r_hi.z, r_hi.w}};
 
     // the projection this lane evaluates for its quad: source view min(pl, NV-1) + 1
     const int myv = pl < NV ? pl : NV - 1;
@@ -144,30 +144,43 @@ __global__ __launch_bounds__(256) void warp_variance_tc_kernel(const void* __res
             }
         }
         const Samp next = make_samp(qx, qy, qz, tx, ty, tz, dv[min(d + 1, D - 1)], sx, sy, h, w, 0, 0, w, h);
-        float4 S_lo = ref_lo, S_hi = ref_hi;
-        float4 Q_lo = make_float4(ref_lo.x * ref_lo.x, ref_lo.y * ref_lo.y, ref_lo.z * ref_lo.z, ref_lo.w * ref_lo.w);
-        float4 Q_hi = make_float4(ref_hi.x * ref_hi.x, ref_hi.y * ref_hi.y, ref_hi.z * ref_hi.z, ref_hi.w * ref_hi.w);
+        // blend + accumulate on channel pairs: v_pk_fma_f32 / v_pk_mul_f32 do two lanes' worth per issue
+        f32x2 S[4], Q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S[j] = refp[j];
+            Q[j] = refp[j] * refp[j];
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float w00 = quad_bcast(mine.w00, v), w01 = quad_bcast(mine.w01, v);
             const float w10 = quad_bcast(mine.w10, v), w11 = quad_bcast(mine.w11, v);
+            const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x4 a = tap[v][0][hh], b = tap[v][1][hh], c = tap[v][2][hh], e = tap[v][3][hh];
-                float4 wv;
-                wv.x = fmaf(a.x, w00, fmaf(b.x, w01, fmaf(c.x, w10, e.x * w11)));
-                wv.y = fmaf(a.y, w00, fmaf(b.y, w01, fmaf(c.y, w10, e.y * w11)));
-                wv.z = fmaf(a.z, w00, fmaf(b.z, w01, fmaf(c.z, w10, e.z * w11)));
-                wv.w = fmaf(a.w, w00, fmaf(b.w, w01, fmaf(c.w, w10, e.w * w11)));
-                if (hh == 0) accum(S_lo, Q_lo, wv);
-                else accum(S_hi, Q_hi, wv);
+            for (int j = 0; j < 4; ++j) {
+                const int hh = j >> 1, q = (j & 1) * 2;
+                const f32x2 a = {tap[v][0][hh][q], tap[v][0][hh][q + 1]};
+                const f32x2 bb = {tap[v][1][hh][q], tap[v][1][hh][q + 1]};
+                const f32x2 c = {tap[v][2][hh][q], tap[v][2][hh][q + 1]};
+                const f32x2 e = {tap[v][3][hh][q], tap[v][3][hh][q + 1]};
+                // a*w00 + (b*w01 + (c*w10 + e*w11)) -- the plain kernel's nesting, per component
+                const f32x2 wv = __builtin_elementwise_fma(a, W00, __builtin_elementwise_fma(bb, W01,
+                                 __builtin_elementwise_fma(c, W10, e * W11)));
+                S[j] = S[j] + wv;
+                Q[j] = __builtin_elementwise_fma(wv, wv, Q[j]);
             }
         }
         if (live) {
-            const float4 o_lo = variance4(S_lo, Q_lo, inv_n), o_hi = variance4(S_hi, Q_hi, inv_n);
-            const size_t o = ((size_t)pl * V0 + (size_t)d * hw + p) * 8;
-            St<DT>::store4(var, o, (f32x4){o_lo.x, o_lo.y, o_lo.z, o_lo.w});
-            St<DT>::store4(var, o + 4, (f32x4){o_hi.x, o_hi.y, o_hi.z, o_hi.w});
+            f32x2 o[4];
+            const f32x2 IN = {inv_n, inv_n};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // var = Q/N - (S/N)^2   (models/mvsnet.py:177)
+                const f32x2 m = S[j] * IN;
+                o[j] = __builtin_elementwise_fma(-m, m, Q[j] * IN);
+            }
+            const size_t oo = ((size_t)pl * V0 + (size_t)d * hw + p) * 8;
+            St<DT>::store4(var, oo, (f32x4){o[0].x, o[0].y, o[1].x, o[1].y});
+            St<DT>::store4(var, oo + 4, (f32x4){o[2].x, o[2].y, o[3].x, o[3].y});
         }
         mine = next;
     }
