@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--fused-conv0", action="store_true",
                     help="staged mode: use the fused mvs_warp_conv0 kernel (variance volume never "
                          "materialised) instead of separate warp+variance and conv0 kernels")
+    ap.add_argument("--stage-every", type=int, default=6,
+                    help="every M-th timed step goes through the per-stage C-ABI calls with HIP events "
+                         "(per-kernel durations); the others are one mvs_depth_infer call")
     ap.add_argument("--fused-call", action="store_true",
                     help="time mvs_depth_infer (one C call per map) instead of the staged calls")
     args = ap.parse_args()
@@ -184,7 +187,18 @@ def main():
         ws = wss[k % S]
         _lib.depth_infer(feats, proj, dv, blob, ws, out[k, 0], out[k, 1], dtype=dt)
 
-    step_one = step_fused if args.fused_call else step_staged
+    # Every step is one mvs_depth_infer call per map (what the drop-in's forward enqueues), except
+    # every `stage_every`-th step, which issues the same kernels through the per-stage C-ABI calls
+    # with a HIP event after each: those steps give the live per-kernel durations of the timed region.
+    # (An event between every pair of kernels costs ~3 us each, 4 % of a 1.3 ms map, so it is not put
+    # around all of them.)  --fused-call: never staged; --stage-every 1: always staged.
+    M = 0 if args.fused_call else (1 if fused else max(1, args.stage_every))
+    staged_steps = [k for k in range(K) if M and k % M == 0]
+
+    def step_one(k, ev=None):
+        if M and k % M == 0:
+            return step_staged(k, ev)
+        return step_fused(k)
 
     def step(k, ev=None):
         if S == 1:
@@ -223,9 +237,9 @@ def main():
     # ---- per-stage durations from the events of the timed steps -----------------------------
     costs = stage_costs(N, D, h, w, es)
     stages = {}
-    if not args.fused_call:
+    if staged_steps:
         for si, name in enumerate(stage_names):
-            ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in range(K)]))
+            ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in staged_steps]))
             ent = {"ms": round(ms, 4)}
             c = costs.get(name)
             if c and ms > 0:
@@ -339,7 +353,10 @@ def main():
                                    "resident in HBM -> depth+confidence)",
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",
-                       "call": "single mvs_depth_infer call" if args.fused_call else "staged C-ABI calls",
+                       "call": "single mvs_depth_infer call" if args.fused_call else
+                               (f"one mvs_depth_infer call per map; every {M}th map through the per-stage C-ABI "
+                                f"calls with HIP events ({len(staged_steps)} of {K} steps)" if M > 1
+                                else "staged C-ABI calls with HIP events"),
                        "warp_conv0": "fused kernel" if (fused or os.environ.get("MVS_FUSE") == "1") else "separate kernels",
                        "streams": S},
             "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),
