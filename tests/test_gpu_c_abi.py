@@ -1,0 +1,42 @@
+"""The C ABI driven from a plain-C host process (tools/c_abi_demo/demo.c: gcc + HIP runtime API, no
+Python / torch in that process): same numbers as the oracle, errors as status codes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, rel_l1
+from oracle import oracle as orc
+from scene_3dreconstruction_mvsnet_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_host_runs_depth_infer(tmp_path):
+    demo = os.path.join(REPO, "tools", "c_abi_demo", "demo")
+    if not os.path.exists(demo):
+        subprocess.check_call(["make", "-C", os.path.dirname(demo)])
+    N, D, h, w = 3, 16, 24, 40
+    feats = synthetic.random_features(N, 32, h, w, seed=4)
+    proj = synthetic.cameras(N, h, w, yaw_deg=1.0)
+    dv = synthetic.depth_values(D)
+    sd = synthetic.random_costreg_state(seed=4)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(np.array([N, D, h, w], np.int32).tobytes())
+        for a in (feats, proj, dv):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+        for key in _lib.CONV_WEIGHT_KEYS:
+            f.write(np.ascontiguousarray(sd[key], np.float32).tobytes())
+        for pre in _lib.BN_PREFIXES:
+            for suffix in ("weight", "bias", "running_mean", "running_var"):
+                f.write(np.ascontiguousarray(sd[f"{pre}.{suffix}"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(sd["prob.bias"], np.float32).tobytes())
+    r = subprocess.run([demo, _lib.LIB_PATH, fin, fout], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "must be positive multiples of 8" in r.stdout      # the bad-shape message came back as text
+    out = np.fromfile(fout, np.float32).reshape(2, h, w)
+    depth_o, conf_o = orc.depth_infer(feats, proj, dv, sd)
+    assert rel_l1(out[0], depth_o) < 1e-5
+    assert (np.abs(out[1] - conf_o) > 5e-3).mean() < 0.02
