@@ -40,3 +40,25 @@ def test_plain_c_host_runs_depth_infer(tmp_path):
     depth_o, conf_o = orc.depth_infer(feats, proj, dv, sd)
     assert rel_l1(out[0], depth_o) < 1e-5
     assert (np.abs(out[1] - conf_o) > 5e-3).mean() < 0.02
+
+
+def test_rccl_backend_initialises_and_gathers_on_this_box(tmp_path):
+    """bench.py --gpus N initialises torch.distributed with backend "nccl" (= RCCL) and gathers the
+    per-rank maps with all_gather_into_tensor; a one-GPU box can only run the 1-rank form of exactly
+    those calls, which still exercises the RCCL init path and the device-tensor collective."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "src = torch.arange(2 * 2 * 8 * 8, dtype=torch.float32, device=dev).reshape(2, 2, 8, 8)\n"
+        "out = torch.empty_like(src)\n"
+        "dist.all_gather_into_tensor(out, src)\n"
+        "dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(out, src)\n"
+        "t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "assert float(t.item()) == 1.5\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
