@@ -210,6 +210,10 @@ def main():
         step(i % K)
     torch.cuda.synchronize()
     if world > 1:
+        # untimed warm-up of the result gather: RCCL builds its rings / buffers on the first
+        # collective of a given kind, which must not land inside the timed region
+        sharding.gather_maps(out, world * K, rank, world)
+        torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
