@@ -809,9 +809,9 @@ struct DeconvG {
     static constexpr int IN_TILE_FLOATS = HZ * HY * HXP * VS;
     static constexpr int NPIECE = HZ * HY * HX * 2;
     static constexpr int PPT = (NPIECE + 255) / 256;
-    // epilogue staging tile: the block's 2BZ x 4BY x 16BX output voxels x COUT channels, rows padded
+    // epilogue staging tile: one z parity of the block's 2BZ x 4BY x 16BX output voxels x COUT channels, rows padded
     // (16 floats per 8 voxels, row pitch = 16 mod 32) so that the accumulator scatter is conflict-free
-    static constexpr int OZ = 2 * BZ, OY = 4 * BY, OX = 16 * BX;
+    static constexpr int OZ = BZ, OY = 4 * BY, OX = 16 * BX;  // one z parity at a time
     static constexpr int RP0 = OX * COUT + 16 * (OX / 8);
     static constexpr int RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
     static constexpr int OUT_TILE_FLOATS = OZ * OY * RP;
@@ -957,11 +957,39 @@ __global__ __launch_bounds__(256) void deconvg_mfma_kernel(
     // owns whole voxels of one C8 plane (8 channels = 32 B) and does the skip add with 16-byte
     // loads / stores that are contiguous across the wave (the scalar form cost 0.036 of conv11's
     // 0.090 ms in exposed skip-load latency and 4-byte stores).
-    __syncthreads();  // all waves are done reading the input tile
-    {
-        const int nn = 16 * nt + (lane & 15);
-        const int px = nn / COUT, co = nn % COUT;
-        const float bv = bias[co];
+    // Two passes, one per output z parity (halves the staging tile: conv11 43 -> 21.5 KB, so a fourth
+    // block fits per CU); in each pass the skip values are requested first, the scatter and its
+    // barrier run while they are in flight.
+    const int Do = 2 * Di;
+    const int nn = 16 * nt + (lane & 15);
+    const int px = nn / COUT, co = nn % COUT;
+    const float bv = bias[co];
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+        // units of this pass: (plane, oz_l in [0,BZ), oy, ox), 8 channels each
+        size_t uo[G::UPT];
+        int usrc[G::UPT];
+        f32x4 sk0[G::UPT], sk1[G::UPT];
+        float sk16[G::UPT][8];
+#pragma unroll
+        for (int j = 0; j < G::UPT; ++j) {
+            const int u = tid + j * 256;
+            const int ox = u % G::OX;
+            int t = u / G::OX;
+            const int oy = t % G::OY; t /= G::OY;
+            const int ozl = t % BZ, pl = t / BZ;
+            const int gz = 2 * (iz0 + ozl) + pz, gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
+            const bool ok = u < G::NUNIT && gz < Do && gy < Ho && gx < Wo;
+            usrc[j] = ok ? (ozl * G::OY + oy) * G::RP + ox * COUT + (ox >> 3) * 16 + pl * 8 : -1;
+            uo[j] = ok ? ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8 : 0;
+            if constexpr (DT == MVS_F32) {
+                sk0[j] = St<DT>::load4(skip, uo[j]);
+                sk1[j] = St<DT>::load4(skip, uo[j] + 4);
+            } else {
+                load8_16<DT>(skip, uo[j], sk16[j]);
+            }
+        }
+        __syncthreads();  // input tile (pass 0) / previous pass's staging tile fully consumed
 #pragma unroll
         for (int i = 0; i < G::MPW; ++i) {
             const int t = mg * G::MPW + i;
@@ -972,39 +1000,25 @@ __global__ __launch_bounds__(256) void deconvg_mfma_kernel(
                 const int ly = 2 * ty + (m >> 3), lx = 8 * tx + (m & 7);  // input voxel inside the block tile
                 const int ox = 2 * lx + px;
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls) {
-                    const int oz = 2 * tz + (cls >> 1), oy = 2 * ly + (cls & 1);
-                    tile[(oz * G::OY + oy) * G::RP + ox * COUT + (ox >> 3) * 16 + co] =
-                        fmaxf(acc[cls][i][e] + bv, 0.0f);
-                }
+                for (int py = 0; py < 2; ++py)
+                    tile[(tz * G::OY + 2 * ly + py) * G::RP + ox * COUT + (ox >> 3) * 16 + co] =
+                        fmaxf(acc[2 * pz + py][i][e] + bv, 0.0f);
             }
         }
-    }
-    __syncthreads();
-    const int Do = 2 * Di;
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < G::UPT; ++j) {
-        const int u = tid + j * 256;
-        if (u >= G::NUNIT) break;
-        const int ox = u % G::OX;
-        int t = u / G::OX;
-        const int oy = t % G::OY; t /= G::OY;
-        const int oz = t % G::OZ, pl = t / G::OZ;
-        const int gz = 2 * iz0 + oz, gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
-        if (gz >= Do || gy >= Ho || gx >= Wo) continue;
-        const float* src = tile + (oz * G::OY + oy) * G::RP + ox * COUT + (ox >> 3) * 16 + pl * 8;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-        const size_t o = ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8;
-        if constexpr (DT == MVS_F32) {
-            const f32x4 s0 = St<DT>::load4(skip, o), s1 = St<DT>::load4(skip, o + 4);
-            St<DT>::store4(y, o, lo + s0);
-            St<DT>::store4(y, o + 4, hi + s1);
-        } else {
-            float sk[8];
-            load8_16<DT>(skip, o, sk);
-            const float v[8] = {lo.x + sk[0], lo.y + sk[1], lo.z + sk[2], lo.w + sk[3],
-                                hi.x + sk[4], hi.y + sk[5], hi.z + sk[6], hi.w + sk[7]};
-            store8_16<DT>(y, o, v);
+        for (int j = 0; j < G::UPT; ++j) {
+            if (usrc[j] < 0) continue;
+            const float* src = tile + usrc[j];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            if constexpr (DT == MVS_F32) {
+                St<DT>::store4(y, uo[j], lo + sk0[j]);
+                St<DT>::store4(y, uo[j] + 4, hi + sk1[j]);
+            } else {
+                const float v[8] = {lo.x + sk16[j][0], lo.y + sk16[j][1], lo.z + sk16[j][2], lo.w + sk16[j][3],
+                                    hi.x + sk16[j][4], hi.y + sk16[j][5], hi.z + sk16[j][6], hi.w + sk16[j][7]};
+                store8_16<DT>(y, uo[j], v);
+            }
         }
     }
 }
