@@ -113,42 +113,52 @@ def _completer(cq: "queue.Queue", pool, futures: list, device):
         futures.append(pool.submit(_write_sample, payload + (depth, conf)))
 
 
-def _loader(dataset, indices, device, copy_stream, q: "queue.Queue"):
-    """Producer thread: decode sample i+1.. on the CPU and copy it to the device on `copy_stream`
-    while the GPU computes sample i."""
+def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: int = 16):
+    """Producer thread: dataset items are decoded by `decoders` helper threads running ahead (PIL's
+    PNG/JPEG decoding releases the GIL), handed over in order, and copied to the device on
+    `copy_stream` while the GPU computes the previous sample."""
+    from concurrent.futures import ThreadPoolExecutor
     try:
-        for idx in indices:
-            t0 = _now()
-            s = dataset[idx]
-            _tick("loader.dataset", t0)
-            t0 = _now()
-            src = [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None]
-                   for k in ("imgs", "proj_matrices", "depth_values")]
-            _tick("loader.prep", t0)
-            t0 = _now()
-            with torch.cuda.stream(copy_stream):
-                # pageable -> device: the HIP runtime stages through its own pinned chunks; measured
-                # faster here than an explicit host copy into a torch pinned buffer (1.5-2 GB/s)
-                dev = [t.to(device) for t in src]
-                ready = torch.cuda.Event()
-                ready.record(copy_stream)
-            _tick("loader.h2d", t0)
-            t0 = _now()
-            q.put((idx, s, dev, ready))
-            _tick("loader.q_put", t0)
+        with ThreadPoolExecutor(max_workers=max(1, decoders)) as pool:
+            ahead = 2 * max(1, decoders)
+            futs = {}
+            nxt = 0
+            for pos, idx in enumerate(indices):
+                while nxt < len(indices) and nxt < pos + ahead:
+                    futs[nxt] = pool.submit(dataset.__getitem__, indices[nxt])
+                    nxt += 1
+                t0 = _now()
+                s = futs.pop(pos).result()
+                _tick("loader.dataset_wait", t0)
+                t0 = _now()
+                src = [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None]
+                       for k in ("imgs", "proj_matrices", "depth_values")]
+                _tick("loader.prep", t0)
+                t0 = _now()
+                with torch.cuda.stream(copy_stream):
+                    # pageable -> device: the HIP runtime stages through its own pinned chunks; measured
+                    # faster here than an explicit host copy into a torch pinned buffer (1.5-2 GB/s)
+                    dev = [t.to(device) for t in src]
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
+                _tick("loader.h2d", t0)
+                t0 = _now()
+                q.put((idx, s, dev, ready))
+                _tick("loader.q_put", t0)
     except BaseException as e:  # noqa: BLE001 - re-raised by the consumer
         q.put(e)
     q.put(None)
 
 
 def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 1, device=None,
-                       writers: int = 16, save_images: bool = True):
+                       writers: int = 16, save_images: bool = True, decoders: int = 16):
     """Run `model` over dataset items rank::world and write the reference's per-view files.
 
     dataset[i] -> dict with "imgs" [N,3,H,W], "proj_matrices" [N,4,4], "depth_values" [D],
     "filename" and optionally "intrinsics" / "extrinsics" (lists; entry 0 = reference view), as
     the reference's eval datasets return them (datasets/dataloader_eval.py:171-176).
-    Stages that overlap: a loader thread (dataset decode + H2D on a copy stream), the forward passes
+    Stages that overlap: `decoders` threads running dataset[i] ahead of time, a loader thread (H2D on
+    a copy stream), the forward passes
     on the current stream, one completion thread (D2H of finished samples on its own stream) and
     `writers` threads that encode the PFM / PNG / cam files.  MVS_DRIVER_TRACE=1 prints where the
     host time went.
@@ -162,7 +172,7 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
     with torch.cuda.device(device):
         copy_stream = torch.cuda.Stream(device)
         compute = torch.cuda.current_stream(device)
-        th = threading.Thread(target=_loader, args=(dataset, mine, device, copy_stream, q), daemon=True)
+        th = threading.Thread(target=_loader, args=(dataset, mine, device, copy_stream, q, decoders), daemon=True)
         th.start()
         futures = []
         cq: "queue.Queue" = queue.Queue(maxsize=4 * max(1, writers))

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Driver throughput from an ON-DISK dataset (PNG decode + cam parsing per view, as in a real eval):
+writes a synthetic DTU-style scan at cfg2 image size, then runs EvalDataset -> save_depth_sharded with
+1 and 8 decoder threads.  Usage: python tools/time_dataset_driver.py [n_views=24]"""
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from scene_3dreconstruction_mvsnet_amd import MVSNet, synthetic  # noqa: E402
+from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset  # noqa: E402
+from scene_3dreconstruction_mvsnet_amd.eval_driver import save_depth_sharded, write_cam  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+H, W = 512, 640
+root = tempfile.mkdtemp(prefix="mvs_ds_")
+data = os.path.join(root, "data")
+os.makedirs(os.path.join(data, "Cameras"))
+os.makedirs(os.path.join(data, "Rectified", "scan1"))
+rng = np.random.default_rng(0)
+# DTU layout (datasets/dataloader_eval.py): images 1200x1600 are rescaled by 0.5... here the files are
+# written at 2x the network size so that the loader's rescale + crop to img_res runs as in a real eval
+K = np.array([[361.5 * 8, 0, W], [0, 360.0 * 8, H], [0, 0, 1]], np.float32)
+for v in range(V):
+    img = (rng.random((H // 8, W // 8, 3)) * 255).astype(np.uint8)
+    Image.fromarray(img).resize((2 * W, 2 * H), Image.BILINEAR).save(
+        os.path.join(data, "Rectified", "scan1", f"rect_{v + 1:03d}_3_r5000.png"))
+    E = np.eye(4, dtype=np.float32)
+    E[0, 3], E[1, 3] = -30.0 * v, 5.0 * v
+    write_cam(os.path.join(data, "Cameras", f"{v:08d}_cam.txt"), K, E, ["425.0", "2.5", "", ""])
+with open(os.path.join(data, "pair.txt"), "w") as f:
+    f.write(f"{V}\n")
+    for v in range(V):
+        src = [(v + d) % V for d in (1, -1, 2, -2, 3, -3)]
+        f.write(f"{v}\n{len(src)} " + " ".join(f"{s} 1.0" for s in src) + "\n")
+listfile = os.path.join(root, "list.txt")
+open(listfile, "w").write("scan1\n")
+ds = EvalDataset(data, listfile, "test", 5, 192, 1.06, img_res=(H, W), dataset_name="dtu")
+dev = torch.device("cuda:0")
+model = MVSNet(refine=False)
+synthetic.randomize_bn_(model, seed=0)
+model = model.to(dev).eval()
+t0 = time.perf_counter()
+ds[0]
+print(f"one dataset item (5 PNG decodes + cams): {(time.perf_counter() - t0) * 1e3:.1f} ms")
+out = os.path.join(root, "out")
+for dec in (1, 8, 16, 32):
+    save_depth_sharded(model, ds, out, device=dev, decoders=dec, save_images=False)
+    t0 = time.perf_counter()
+    save_depth_sharded(model, ds, out, device=dev, decoders=dec, save_images=False)
+    dt = time.perf_counter() - t0
+    print(f"decoders={dec}: {len(ds) / dt:.1f} maps/s ({dt / len(ds) * 1e3:.2f} ms per sample, {len(ds)} samples)")
+shutil.rmtree(root, ignore_errors=True)
