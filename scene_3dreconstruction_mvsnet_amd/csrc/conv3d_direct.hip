@@ -456,8 +456,20 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         return launch_layer_mfma16(layer, x, skip, y, blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][layer],
                                    blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     if (layer == 0)
-        return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
+{
+            // conv0: Winograd F(2,3) along z on the 4x4x1 MFMA (2/3 of the direct form's MFMAs) unless
+            // MVS_CONV0_WINO=0 or one of the direct variants is requested
+            static const bool wino = [] {
+                const char* e = getenv("MVS_CONV0_WINO");
+                const char* p = getenv("MVS_CONV0_PAIR");
+                const char* w8 = getenv("MVS_CONV0_8W");
+                return !(e && e[0] == '0') && !(p && p[0] == '1') && !(w8 && w8[0] == '1');
+            }();
+            if (wino)
+                return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+            return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
                                  dtype, s);
+        }
     if (layer >= 1 && layer <= 6)
         return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi,
                                  dtype, s);
