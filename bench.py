@@ -268,6 +268,13 @@ def main():
                         "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
                         "algorithmic_bytes": c["bytes"]}
+            if dom == "conv0" and storage == "f32" and os.environ.get("MVS_CONV0_WINO", "1") != "0" \
+                    and os.environ.get("MVS_CONV0_PAIR") != "1" and os.environ.get("MVS_CONV0_8W") != "1":
+                roofline["note"] = ("conv0 runs Winograd F(2,3) along z on the fp32 4x4x1 MFMA: it issues 2/3 of "
+                                    "the algorithmic multiply-adds (36.2 of 54.4 GFLOP); `achieved` is the "
+                                    "ALGORITHMIC flops / time as SURVEY 8 d3 defines it, the executed-MFMA "
+                                    "rate is 2/3 of that")
+                roofline["executed_flops"] = c["flops"] * 2 // 3
         else:
             ach = c["bytes"] / ms / 1e6
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
