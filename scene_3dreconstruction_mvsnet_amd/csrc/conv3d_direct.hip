@@ -470,6 +470,16 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
             return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
                                  dtype, s);
         }
+    if (layer == 2 || layer == 4) {
+        // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv0_winograd.hip) unless
+        // MVS_CONV_WINO=0.  conv6 (64 -> 64 on 7,680 voxels) stays direct: with two-plane tiles it has
+        // only 240 blocks for 256 CUs and measured 0.035 vs 0.033 ms.
+        static const bool wz = [] {
+            const char* e = getenv("MVS_CONV_WINO");
+            return !(e && e[0] == '0');
+        }();
+        if (wz) return launch_convwz_mfma(layer, x, y, blob + L.wz_off[layer], blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
+    }
     if (layer >= 1 && layer <= 6)
         return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi,
                                  dtype, s);

@@ -274,7 +274,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
 @pytest.mark.parametrize("env", [
     {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off)
     {"MVS_WARP_LDS": "1"},       # LDS-staged warp+variance kernel
-    {"MVS_CONV0_WINO": "0"},     # conv0 on the direct 4x4x1 MFMA kernel (no Winograd transform)
+    {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
     {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
     {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer

@@ -149,6 +149,20 @@ def test_pack_weights_folds_bn_and_relayouts():
         np.testing.assert_allclose(wz[c, t, tap, half, nt, j, k], G[t][tap, 8 * c + 4 * half + k, 4 * nt + j],
                                    rtol=1e-6, atol=1e-9)
     off += 4 * 4 * 9 * 2 * 2 * 4 * 4
+    # Winograd-z panels of the stride-1 layers 2 and 4: [cin/8][4 t][cout/16][5 k-steps][64 lanes][4]
+    for l in (2, 4):
+        ci, co = layer_ch[l]
+        nch, nt = ci // 8, co // 16
+        panel = blob[off:off + nch * 4 * nt * 5 * 256].reshape(nch, 4, nt, 5, 64, 4)
+        gl = blob[woffs[l]:woffs[l] + 27 * ci * co].reshape(3, 9, ci, co).astype(np.float64)
+        Gl = [gl[0], (gl[0] + gl[1] + gl[2]) / 2, (gl[0] - gl[1] + gl[2]) / 2, gl[2]]
+        for c, t, n, ks, lane, j4 in [(0, 0, 0, 0, 0, 0), (nch - 1, 3, nt - 1, 4, 63, 3), (nch // 2, 1, 0, 2, 21, 1),
+                                      (0, 2, nt - 1, 4, 5, 2)]:
+            g, col = lane >> 4, lane & 15
+            tap = 2 * ks + (g >> 1)
+            want = Gl[t][tap, 8 * c + 4 * (g & 1) + j4, 16 * n + col] if tap < 9 else 0.0
+            np.testing.assert_allclose(panel[c, t, n, ks, lane, j4], want, rtol=1e-6, atol=1e-9)
+        off += nch * 4 * nt * 5 * 256
     assert off * 4 == _lib.query_weights_blob()
 
 
