@@ -101,12 +101,30 @@ __global__ __launch_bounds__(256, 2) void conv0_wz_mfma_kernel(
 
     f32x4 stg[CPT][4];
     f32x4 wst[WPT];
+    // fp32 storage: raw buffer loads -- a piece outside the volume gets a byte offset beyond the
+    // buffer's range and the hardware returns zeros, so the transform needs no select instructions
+    unsigned boff[CPT][4];
+    if constexpr (DT == MVS_F32) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                boff[i][q] = (((okxy >> i) & 1u) && zok[q]) ? (unsigned)((zoff[q] + (size_t)goff[i]) * 4) : 0x80000000u;
+    }
 #define C0W_LOAD(C)                                                                            \
     {                                                                                          \
         const size_t plane = (size_t)(C) * V8;                                                 \
-        _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                        \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                      \
-                stg[i][q] = St<DT>::load4(x, plane + zoff[q] + goff[i]);                       \
+        if constexpr (DT == MVS_F32) {                                                         \
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(               \
+                const_cast<float*>(static_cast<const float*>(x) + plane), (short)0, (int)(V8 * 4), 0x00020000); \
+            _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                    \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                  \
+                    stg[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff[i][q], 0, 0)); \
+        } else {                                                                               \
+            _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                    \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                  \
+                    stg[i][q] = St<DT>::load4(x, plane + zoff[q] + goff[i]);                   \
+        }                                                                                      \
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(bw) + (size_t)(C) * WPIECES;        \
         _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                        \
             wst[i] = wsrc[min(tid + i * 256, WPIECES - 1)];                                    \
@@ -117,10 +135,11 @@ __global__ __launch_bounds__(256, 2) void conv0_wz_mfma_kernel(
         _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                        \
             if (loff[i] >= 0) {                                                                \
                 const bool in = (okxy >> i) & 1u;                                              \
-                const f32x4 d0 = (in && zok[0]) ? stg[i][0] : zero;                            \
-                const f32x4 d1 = (in && zok[1]) ? stg[i][1] : zero;                            \
-                const f32x4 d2 = (in && zok[2]) ? stg[i][2] : zero;                            \
-                const f32x4 d3 = (in && zok[3]) ? stg[i][3] : zero;                            \
+                const bool hw0 = DT == MVS_F32;  /* zeros already delivered by the buffer loads */ \
+                const f32x4 d0 = (hw0 || (in && zok[0])) ? stg[i][0] : zero;                    \
+                const f32x4 d1 = (hw0 || (in && zok[1])) ? stg[i][1] : zero;                    \
+                const f32x4 d2 = (hw0 || (in && zok[2])) ? stg[i][2] : zero;                    \
+                const f32x4 d3 = (hw0 || (in && zok[3])) ? stg[i][3] : zero;                    \
                 *reinterpret_cast<f32x4*>(tile + loff[i]) = d0 - d2;                           \
                 *reinterpret_cast<f32x4*>(tile + PLANE + loff[i]) = d1 + d2;                   \
                 *reinterpret_cast<f32x4*>(tile + 2 * PLANE + loff[i]) = d2 - d1;               \
@@ -227,9 +246,9 @@ static int run_conv0_wz(const void* x, void* y, const float* bw, const float* bi
 
 int launch_conv0_winograd(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                           int dtype, hipStream_t s) {
-    if ((size_t)D * H * W * 8 >= ((size_t)1 << 31))
-        return fail(MVS_ERR_BAD_SHAPE, "conv0_winograd: plane of %zu elements exceeds 31-bit offsets",
-                    (size_t)D * H * W * 8);
+    if ((size_t)D * H * W * 8 * 4 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "conv0_winograd: plane of %zu bytes exceeds 31-bit buffer offsets",
+                    (size_t)D * H * W * 8 * 4);
     MVS_DISPATCH_DTYPE(dtype, (run_conv0_wz<DT>(x, y, bw, bias, D, H, W, s)))
 }
 

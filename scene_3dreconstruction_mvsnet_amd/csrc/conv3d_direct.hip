@@ -465,7 +465,7 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
                 const char* w8 = getenv("MVS_CONV0_8W");
                 return !(e && e[0] == '0') && !(p && p[0] == '1') && !(w8 && w8[0] == '1');
             }();
-            if (wino)
+            if (wino && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31))   // else: direct kernel (64-bit offsets)
                 return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
             return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
                                  dtype, s);
