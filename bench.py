@@ -287,7 +287,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
                 prof = json.load(f)["kernels"]
-            kname = {"conv0": "mvs::conv0_4x4_mfma_kernel<0>", "warp_variance": "mvs::warp_variance_tc_kernel<0, 0, 4>"}
+            kname = {"conv0": ("mvs::conv0_wz_mfma_kernel<0>" if "note" in roofline else "mvs::conv0_4x4_mfma_kernel<0>"), "warp_variance": "mvs::warp_variance_tc_kernel<0, 0, 4>"}
             ent = prof.get(kname.get(roofline["kernel"], ""))
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
