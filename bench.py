@@ -11,9 +11,16 @@ processes its own independent maps (reference views shard embarrassingly, SURVEY
 only collective is one RCCL all-gather of the [K,2,h,w] results at the end (inside the timed
 region).  Rank 0 prints ONE JSON line.
 
-The timed region launches the path stage by stage through the C ABI with HIP events (torch
-events on the launch stream) around every stage, so per-kernel durations -- and the roofline
-figure of the dominant kernel -- are measured live over exactly the timed steps.
+The timed region is K x one mvs_depth_infer call per map (what the drop-in's forward enqueues),
+nothing else.  Per-kernel durations -- and the roofline figure of the dominant kernel -- are
+measured live in the same process right after it: the same kernels on the same inputs issued
+through the per-stage C-ABI calls with a HIP event (torch event on the launch stream) after each.
+(An event between every pair of kernels costs ~3 us, 4 % of a map, so that pass is not `value`.)
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches itself: the parent,
+before any GPU call, starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child process and relays rank 0's JSON line (the reference's counterpart: nn.DataParallel,
+eval.py:309).
 """
 import argparse
 import json
@@ -26,10 +33,10 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
-from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic  # noqa: E402
+# torch and the package are imported inside main(), after the self-launch decision: the parent of a
+# self-launched multi-GPU run never loads the HIP runtime at all.
+CONFIG_NAMES = ("cfg1", "cfg2", "cfg3", "cfg5")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
@@ -58,12 +65,12 @@ def stage_costs(N, D, h, w, es=4):
     return costs
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--config", default="cfg2", choices=CONFIG_NAMES)
     ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"],
                     help="storage dtype of the private volumes (arithmetic is always fp32); default: "
                          "f32 for cfg1/cfg2, bf16 for cfg3, f16 for cfg5 as BASELINE.json names them")
@@ -72,22 +79,63 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams to round-robin independent maps over (each has its own workspace)")
     ap.add_argument("--fused-conv0", action="store_true",
-                    help="staged mode: use the fused mvs_warp_conv0 kernel (variance volume never "
+                    help="staged pass: use the fused mvs_warp_conv0 kernel (variance volume never "
                          "materialised) instead of separate warp+variance and conv0 kernels")
-    ap.add_argument("--stage-every", type=int, default=6,
-                    help="every M-th timed step goes through the per-stage C-ABI calls with HIP events "
-                         "(per-kernel durations); the others are one mvs_depth_infer call")
-    ap.add_argument("--fused-call", action="store_true",
-                    help="time mvs_depth_infer (one C call per map) instead of the staged calls")
-    args = ap.parse_args()
+    ap.add_argument("--staged-steps", type=int, default=10,
+                    help="maps of the per-kernel pass after the timed region (per-stage C-ABI calls with a "
+                         "HIP event after each kernel); 0 = skip it (no `stages` / `roofline` objects)")
+    ap.add_argument("--staged-timed", action="store_true",
+                    help="diagnostic: the TIMED steps go through the per-stage calls with events too")
+    return ap.parse_args(argv)
 
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(args, argv, port=None):
+    """The torchrun command line `python bench.py --gpus N` turns into (one rank per GPU, RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """Parent of a multi-GPU run started without torchrun: never touches the GPU (on this pool a
+    process that has initialised HIP must not exec; a child started before that is fine), starts
+    the ranks as a child process and relays rank 0's JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.run(self_launch_command(args, argv), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode or lines else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with python -m torch.distributed.run (one rank per GPU)")
+
+    global torch, dist, _lib, sharding, synthetic
+    import torch
+    import torch.distributed as dist
+    from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     # MVS_BENCH_REHEARSAL=1: run every rank on cuda:0 with the gloo backend -- a way to exercise
@@ -120,6 +168,9 @@ def main():
     proj = torch.from_numpy(proj_np).to(dev)
     dv = torch.from_numpy(dv_np).to(dev)
     blob = _lib.pack_weights(sd).to(dev)
+    # fraction of the (pixel, depth, source view) sampling points that land inside the source image
+    # (out-of-image taps are cheaper, so the figure travels with every timing)
+    in_image_frac = round(synthetic.in_image_fraction(proj_np, dv_np, h, w), 4)
     S = max(1, args.streams)
     wss = [_lib.alloc_workspace(N, 32, D, h, w, dev, dt) for _ in range(S)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
@@ -129,7 +180,8 @@ def main():
     stage_names = (["relative_proj", "warp_conv0"] + [l[0] for l in LAYERS[1:]] + ["softargmin"]) if fused \
         else (["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"])
     n_ev = len(stage_names) + 1
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(K)]
+    KS = max(0, args.staged_steps)      # maps of the per-kernel event pass after the timed region
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(max(K, KS))]
 
     # Pre-allocated per-stream buffers and pre-bound C calls keep the host ahead of the GPU in the
     # staged mode (no torch allocations or shape logic inside the timed loop).
@@ -187,18 +239,9 @@ def main():
         ws = wss[k % S]
         _lib.depth_infer(feats, proj, dv, blob, ws, out[k, 0], out[k, 1], dtype=dt)
 
-    # Every step is one mvs_depth_infer call per map (what the drop-in's forward enqueues), except
-    # every `stage_every`-th step, which issues the same kernels through the per-stage C-ABI calls
-    # with a HIP event after each: those steps give the live per-kernel durations of the timed region.
-    # (An event between every pair of kernels costs ~3 us each, 4 % of a 1.3 ms map, so it is not put
-    # around all of them.)  --fused-call: never staged; --stage-every 1: always staged.
-    M = 0 if args.fused_call else (1 if fused else max(1, args.stage_every))
-    staged_steps = [k for k in range(K) if M and k % M == 0]
-
-    def step_one(k, ev=None):
-        if M and k % M == 0:
-            return step_staged(k, ev)
-        return step_fused(k)
+    # Timed steps: one mvs_depth_infer call per map (what the drop-in's forward enqueues), maps
+    # round-robin over the S streams (each stream has its own workspace).
+    step_one = step_staged if (args.staged_timed or fused) else step_fused
 
     def step(k, ev=None):
         if S == 1:
@@ -218,7 +261,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
-        step(k, events[k])
+        step(k)
     for st in streams[1:]:
         streams[0].wait_stream(st)
     if world > 1:
@@ -238,10 +281,17 @@ def main():
     maps_per_s = world * K / elapsed
     ms_per_step = elapsed / K * 1e3
 
-    # ---- per-stage durations from the events of the timed steps -----------------------------
+    # ---- per-kernel durations: the same kernels on the same inputs through the per-stage C-ABI
+    # calls, a HIP event (on the launch stream) after each, one stream, right after the timed region
     costs = stage_costs(N, D, h, w, es)
     stages = {}
+    staged_steps = list(range(KS))
     if staged_steps:
+        step_staged(0)
+        torch.cuda.synchronize()
+        for k in staged_steps:
+            step_staged(k % K, events[k])
+        torch.cuda.synchronize()
         for si, name in enumerate(stage_names):
             ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in staged_steps]))
             ent = {"ms": round(ms, 4)}
@@ -364,10 +414,11 @@ def main():
                                    "resident in HBM -> depth+confidence)",
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",
-                       "call": "single mvs_depth_infer call" if args.fused_call else
-                               (f"one mvs_depth_infer call per map; every {M}th map through the per-stage C-ABI "
-                                f"calls with HIP events ({len(staged_steps)} of {K} steps)" if M > 1
-                                else "staged C-ABI calls with HIP events"),
+                       "call": ("staged C-ABI calls with HIP events" if step_one is step_staged else
+                                "one mvs_depth_infer call per map") +
+                               (f"; per-kernel durations from {KS} further maps through the per-stage C-ABI "
+                                "calls with HIP events, after the timed region" if KS else ""),
+                       "in_image_frac": in_image_frac,
                        "warp_conv0": "fused kernel" if (fused or os.environ.get("MVS_FUSE") == "1") else "separate kernels",
                        "streams": S},
             "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),

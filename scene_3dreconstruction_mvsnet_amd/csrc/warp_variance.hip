@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256) void warp_variance16_kernel(const void* __rest
     }
 }
 
+// MVS_WARP_DEPTH_FASTEST=1 forces the depth-slab-fastest block order (default: only when the feature
+// maps exceed the L2s), so tests can reach it at small shapes
+static bool force_depth_fastest() {
+    static const bool f = [] {
+        const char* e = getenv("MVS_WARP_DEPTH_FASTEST");
+        return e && e[0] == '1';
+    }();
+    return f;
+}
+
 int launch_warp_variance16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                            int h, int w, int dtype, hipStream_t s) {
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
@@ -295,7 +305,7 @@ int launch_warp_variance16(const void* feats16, const float* rt, const float* dv
         return launch_warp_variance_tc16(feats16, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
-    const bool depth_fastest = (size_t)N * h * w * 64 > ((size_t)24 << 20);
+    const bool depth_fastest = force_depth_fastest() || (size_t)N * h * w * 64 > ((size_t)24 << 20);
     const dim3 grid = depth_fastest ? dim3(nd, np) : dim3(np, nd);
     if (dtype == MVS_F16) {
         if (depth_fastest) warp_variance16_kernel<MVS_F16, true><<<grid, 256, 0, s>>>(feats16, rt, dv, var, N, D, h, w);
@@ -329,7 +339,7 @@ int launch_warp_variance(const float* feats_p, const float* rt, const float* dv,
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
     float* v = static_cast<float*>(var);
     // all views' features (N x 32 channels x fp32) against the 32 MB of aggregate L2
-    const bool depth_fastest = (size_t)N * h * w * 128 > ((size_t)24 << 20);
+    const bool depth_fastest = force_depth_fastest() || (size_t)N * h * w * 128 > ((size_t)24 << 20);
     if (depth_fastest) {
         dim3 grid(nd, np);
         if (dtype == MVS_F32) warp_variance_kernel<MVS_F32, true><<<grid, 256, 0, s>>>(feats_p, rt, dv, v, N, D, h, w);

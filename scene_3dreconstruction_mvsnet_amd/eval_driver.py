@@ -95,22 +95,31 @@ def _now():
     return 0.0
 
 
-def _completer(cq: "queue.Queue", pool, futures: list, device):
+def _completer(cq: "queue.Queue", pool, futures: list, device, errors: list):
     """Single thread that copies each finished sample's maps to the host (own stream, ordered after
-    the forward by an event) and hands them to the writer pool."""
-    d2h = torch.cuda.Stream(device)
+    the forward by an event) and hands them to the writer pool.  A failure is stored in `errors`
+    (re-raised by save_depth_sharded); the thread then keeps draining the queue so that the
+    producer never blocks on a full queue behind a dead consumer."""
+    d2h = None
     while True:
         job = cq.get()
         if job is None:
             return
-        done, out, payload = job
-        t0 = _now()
-        with torch.cuda.stream(d2h):
-            d2h.wait_event(done)
-            depth = out["depth"][0].to("cpu", non_blocking=False)
-            conf = out["photometric_confidence"][0].to("cpu", non_blocking=False)
-        _tick("completer.d2h", t0)
-        futures.append(pool.submit(_write_sample, payload + (depth, conf)))
+        if errors:
+            continue
+        try:
+            if d2h is None:
+                d2h = torch.cuda.Stream(device)
+            done, out, payload = job
+            t0 = _now()
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(done)
+                depth = out["depth"][0].to("cpu", non_blocking=False)
+                conf = out["photometric_confidence"][0].to("cpu", non_blocking=False)
+            _tick("completer.d2h", t0)
+            futures.append(pool.submit(_write_sample, payload + (depth, conf)))
+        except BaseException as e:  # noqa: BLE001 - re-raised by save_depth_sharded
+            errors.append(e)
 
 
 def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: int = 16):
@@ -177,7 +186,8 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
         futures = []
         cq: "queue.Queue" = queue.Queue(maxsize=4 * max(1, writers))
         with ThreadPoolExecutor(max_workers=max(1, writers)) as pool, torch.no_grad():
-            comp = threading.Thread(target=_completer, args=(cq, pool, futures, device), daemon=True)
+            errors: list = []
+            comp = threading.Thread(target=_completer, args=(cq, pool, futures, device, errors), daemon=True)
             comp.start()
             try:
                 while True:
@@ -188,6 +198,8 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
                         break
                     if isinstance(item, BaseException):
                         raise item
+                    if errors:      # the completer failed: stop enqueuing forwards
+                        break
                     idx, s, dev, ready = item
                     compute.wait_event(ready)
                     for t in dev:
@@ -208,6 +220,9 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
             finally:
                 cq.put(None)
                 comp.join()
+            if errors:
+                raise RuntimeError("save_depth_sharded: copying a finished depth map to the host / handing "
+                                   "it to the writers failed; the output tree is incomplete") from errors[0]
             for f in futures:
                 f.result()
         th.join()

@@ -105,69 +105,94 @@ class MVSNet(nn.Module):
         # per-device caches; plain attributes so nn.DataParallel replicas share them
         self._cache_lock = threading.Lock()
         self._blob_cache = {}       # device index -> (param versions, device blob tensor)
-        self._workspace_cache = {}  # (device index, N, D, h, w) -> uint8 device tensor
+        self._workspace_cache = {}  # (device index, stream, N, D, h, w, dtype) -> uint8 device tensor
 
     # The lock and the device caches are process-local: drop them when the module is pickled or
     # deep-copied (torch.save(model), copy.deepcopy) and start the copy with empty caches.
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_cache_lock", "_blob_cache", "_workspace_cache"):
+        for k in ("_cache_lock", "_blob_cache", "_workspace_cache", "_dp_source"):
             state.pop(k, None)
         return state
+
+    # nn.DataParallel runs forward on replicas made by torch.nn.parallel.replicate() (eval.py:309
+    # wraps the model even on one GPU).  A replica's parameters are plain attributes -- broadcast
+    # copies, not `_parameters` entries -- so `state_dict()` / `parameters()` on it see only the BN
+    # buffers, and its tensors change address every forward.  Weights are therefore always packed
+    # from the SOURCE module, which every replica remembers here (a `__dict__` entry, not a
+    # registered sub-module); the caches are shared with it through the shallow `__dict__` copy.
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_source"] = self._source()
+        return replica
+
+    def _source(self):
+        return self.__dict__.get("_dp_source", self)
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self._cache_lock = threading.Lock()
         self._blob_cache = {}
         self._workspace_cache = {}
+        self.__dict__.pop("_dp_source", None)
 
     # -- caches ------------------------------------------------------------------------------
-    def _param_versions(self, mod=None):
-        cr = self.cost_regularization if mod is None else mod
-        return tuple((t.data_ptr(), t._version) for t in list(cr.parameters()) + list(cr.buffers()))
+    @staticmethod
+    def _param_versions(mod):
+        return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
+
+    def _packable_state(self, which):
+        """CPU copy of the source module's `feature` / `cost_regularization` state dict (never a
+        replica's: see _replicate_for_data_parallel)."""
+        mod = getattr(self._source(), which)
+        return {k: v.detach().cpu() for k, v in mod.state_dict().items()}
 
     def _feature_blob(self, device):
         key = ("feature", device.index if device.index is not None else torch.cuda.current_device())
-        versions = self._param_versions(self.feature)
+        versions = self._param_versions(self._source().feature)
         with self._cache_lock:
             hit = self._blob_cache.get(key)
             if hit is not None and hit[0] == versions:
                 return hit[1]
-            state = {k: v.detach().cpu() for k, v in self.feature.state_dict().items()}
-            blob = _lib.pack_feature_weights(state, eps=self.feature.conv0.bn.eps).to(device)
+            state = self._packable_state("feature")
+            blob = _lib.pack_feature_weights(state, eps=self._source().feature.conv0.bn.eps).to(device)
             self._blob_cache[key] = (versions, blob)
             return blob
 
-    def _forward_workspace(self, device, N, H, W, D, dtype):
-        key = ("fwd", device.index, N, H, W, D, dtype)
+    # One workspace per (device, stream, shape): forwards enqueued on different streams (user side
+    # streams, DataParallel worker threads) must not share the variance / activation volumes --
+    # nothing would order them -- while consecutive forwards on one stream re-use one allocation.
+    _MAX_CACHED_WORKSPACES = 8   # least recently used entries beyond this are dropped
+
+    def _cached_workspace(self, key, nbytes_fn, device):
         with self._cache_lock:
-            ws = self._workspace_cache.get(key)
+            ws = self._workspace_cache.pop(key, None)
             if ws is None:
-                ws = torch.empty(_lib.query_forward_workspace(N, H, W, D, dtype), dtype=torch.uint8,
-                                 device=device)
-                self._workspace_cache[key] = ws
+                ws = torch.empty(nbytes_fn(), dtype=torch.uint8, device=device)
+            self._workspace_cache[key] = ws   # (re-)inserted last = most recently used
+            while len(self._workspace_cache) > self._MAX_CACHED_WORKSPACES:
+                self._workspace_cache.pop(next(iter(self._workspace_cache)))
             return ws
+
+    def _forward_workspace(self, device, N, H, W, D, dtype):
+        key = ("fwd", device.index, _lib._stream(device), N, H, W, D, dtype)
+        return self._cached_workspace(key, lambda: _lib.query_forward_workspace(N, H, W, D, dtype), device)
 
     def _weights_blob(self, device):
         key = device.index if device.index is not None else torch.cuda.current_device()
-        versions = self._param_versions()
+        versions = self._param_versions(self._source().cost_regularization)
         with self._cache_lock:
             hit = self._blob_cache.get(key)
             if hit is not None and hit[0] == versions:
                 return hit[1]
-            state = {k: v.detach().cpu() for k, v in self.cost_regularization.state_dict().items()}
-            blob = _lib.pack_weights(state, eps=self.cost_regularization.bn_eps()).to(device)
+            state = self._packable_state("cost_regularization")
+            blob = _lib.pack_weights(state, eps=self._source().cost_regularization.bn_eps()).to(device)
             self._blob_cache[key] = (versions, blob)
             return blob
 
     def _workspace(self, device, N, D, h, w, dtype):
-        key = (device.index, N, D, h, w, dtype)
-        with self._cache_lock:
-            ws = self._workspace_cache.get(key)
-            if ws is None:
-                ws = _lib.alloc_workspace(N, 32, D, h, w, device, dtype)
-                self._workspace_cache[key] = ws
-            return ws
+        key = (device.index, _lib._stream(device), N, D, h, w, dtype)
+        return self._cached_workspace(key, lambda: _lib.query_workspace(N, 32, D, h, w, dtype), device)
 
     # -- forward -----------------------------------------------------------------------------
     def forward(self, imgs, proj_matrices, depth_values):

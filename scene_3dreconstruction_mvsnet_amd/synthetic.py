@@ -61,6 +61,29 @@ def cameras(nviews: int, h: int, w: int, baseline=(-30.0, 5.0, 0.0),
     return np.stack(projs).astype(np.float32)
 
 
+def in_image_fraction(proj: np.ndarray, dv: np.ndarray, h: int, w: int) -> float:
+    """Fraction of the (pixel, depth, source view) sampling points of the homography warp
+    (models/module.py:107-136) that fall inside the source image, i.e. have at least one in-bounds
+    bilinear tap.  Host-side bookkeeping in float64, not part of the data path."""
+    proj = np.asarray(proj, np.float64)
+    n = proj.shape[0]
+    if n < 2:
+        return 1.0
+    dv = np.asarray(dv, np.float64)
+    y, x = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    xyz = np.stack([x.ravel(), y.ravel(), np.ones(h * w)])                 # [3, hw]
+    inside = 0
+    for v in range(1, n):
+        rel = proj[v] @ np.linalg.inv(proj[0])
+        q = rel[:3, :3] @ xyz                                               # [3, hw]
+        p = q[:, None, :] * dv[None, :, None] + rel[:3, 3][:, None, None]   # [3, D, hw]
+        with np.errstate(all="ignore"):
+            ix = p[0] / p[2] * (w / (w - 1.0)) - 0.5
+            iy = p[1] / p[2] * (h / (h - 1.0)) - 0.5
+        inside += int(((ix > -1) & (ix < w) & (iy > -1) & (iy < h)).sum())
+    return inside / float((n - 1) * dv.shape[0] * h * w)
+
+
 def smooth_images(nviews: int, H: int, W: int, seed: int = 0, coarse: int = 8) -> np.ndarray:
     """[N,3,H,W] float32 in [0,1]: seeded low-res noise, bilinear upsampled."""
     g = torch.Generator().manual_seed(seed)

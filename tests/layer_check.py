@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Child-process helper: every CostRegNet layer + the variance volume against the oracle at the
+shape given on the command line (D h w), under whatever kernel-selection environment the parent
+set (read once per process): MVS_PERSIST_CUS=1 forces the persistent conv1 kernel at small shapes,
+MVS_WARP_DEPTH_FASTEST=1 the depth-slab-fastest block order of the warp kernels."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+from oracle import oracle as orc  # noqa: E402
+from scene_3dreconstruction_mvsnet_amd import _lib, synthetic  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def main():
+    D, h, w = (int(v) for v in sys.argv[1:4])
+    storages = sys.argv[4:] or ["f32"]
+    sd = synthetic.random_costreg_state(seed=13)
+    blob = _lib.pack_weights(sd).to(DEV)
+    rng = np.random.default_rng(17)
+    worst = 0.0
+    for storage in storages:
+        code = _lib.dtype_code(storage)
+        tdt = _lib.TORCH_DTYPES[code]
+        q = lambda t: orc.round_storage(t, storage)  # noqa: E731
+        eps = {"f32": 0.0, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[storage]
+        # variance volume, N = 3 and 5 (tap-cache kernel) and 7 (plain kernel)
+        for N in (3, 5, 7):
+            feats = synthetic.random_features(N, 32, h, w, seed=N)
+            proj = synthetic.cameras(N, h, w, yaw_deg=1.0)
+            dv = synthetic.depth_values(D)
+            ws = _lib.alloc_workspace(N, 32, D, h, w, DEV, code)
+            var = _lib.warp_variance(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), ws, dtype=code)
+            got = _lib.from_c8(var.float()).cpu().numpy()
+            want = orc.variance_volume(feats, proj, dv) if storage == "f32" else \
+                q(orc.variance_volume(q(feats), proj, dv))
+            np.testing.assert_allclose(got, want, rtol=eps, atol=5e-4)
+        for layer in range(11):
+            ci, co = _lib._LAYER_CH[layer]
+            x = q(rng.standard_normal((ci, D, h, w)).astype(np.float32))
+            key = _lib.CONV_WEIGHT_KEYS[layer]
+            xt = _lib.to_c8(cu(x)).to(tdt)
+            if layer == 10:
+                want = orc.conv3d(x, sd[key], bias=sd["prob.bias"], bn=None, relu=False)[0]
+                got = _lib.conv_layer(10, xt, None, blob, dtype=code).cpu().numpy()
+            elif layer >= 7:
+                skip = q(rng.standard_normal((co, 2 * D, 2 * h, 2 * w)).astype(np.float32))
+                if storage == "f32":
+                    want = skip + orc.deconv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]))
+                else:
+                    wf, sh = orc._fold(sd, key, _lib.BN_PREFIXES[layer], transposed=True)
+                    wt = np.ascontiguousarray(q(wf).transpose(1, 0, 2, 3, 4))
+                    want = q(skip + np.maximum(orc.deconv3d(x, wt, bn=None, relu=False) + sh[:, None, None, None], 0.0))
+                got = _lib.from_c8(_lib.conv_layer(layer, xt, _lib.to_c8(cu(skip)).to(tdt), blob, dtype=code).float()).cpu().numpy()
+            else:
+                stride = 2 if layer in (1, 3, 5) else 1
+                if storage == "f32":
+                    want = orc.conv3d(x, sd[key], bn=orc._bn(sd, _lib.BN_PREFIXES[layer]), stride=stride)
+                else:
+                    wf, sh = orc._fold(sd, key, _lib.BN_PREFIXES[layer])
+                    want = q(orc.conv3d(x, q(wf), bias=sh, bn=None, stride=stride, relu=True))
+                got = _lib.from_c8(_lib.conv_layer(layer, xt, None, blob, dtype=code).float()).cpu().numpy()
+            scale = max(float(np.abs(want).max()), 1.0)
+            err = float(np.abs(got - want).max()) / scale
+            worst = max(worst, err if storage == "f32" else 0.0)
+            np.testing.assert_allclose(got, want, rtol=2 * eps, atol=3e-4 * scale, err_msg=f"layer {layer} {storage}")
+    env = {k: v for k, v in os.environ.items() if k.startswith("MVS_")}
+    print(f"layer_check {D}x{h}x{w} {storages} env={env} worst fp32 layer error {worst:.2e} x max")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
