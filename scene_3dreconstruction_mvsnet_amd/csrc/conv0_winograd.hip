@@ -33,6 +33,7 @@ constexpr int TY = 8, TX = 32;             // output tile: 2 (the z pair) x 8 x 
 constexpr int HY = TY + 2, HX = TX + 2;
 constexpr int VS = 12;                     // floats per voxel in LDS (8 data + 4 pad)
 constexpr int PLANE = HY * HX * VS;        // one transformed plane: 4080 floats
+static_assert(PLANE % 4 == 0, "planes are addressed in 16-byte units");
 constexpr int TILE_FLOATS = 4 * PLANE;     // 65,280 B
 constexpr int NCOL = HY * HX * 2;          // z-columns of 16-byte pieces: (y, x, half)
 constexpr int CPT = (NCOL + 255) / 256;    // 3 per thread
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void conv0_wz_mfma_kernel(
         const bool ok = col < NCOL && gy >= 0 && gy < H && gx >= 0 && gx < W;
         goff[i] = ok ? (int)(((size_t)gy * W + gx) * 8 + half * 4) : 0;
         okxy |= ok ? (1u << i) : 0u;
-        loff[i] = (col < NCOL) ? v * VS + half * 4 : -1;
+        // in 16-byte units: VS = 12 floats and half * 4 are multiples of 4, and saying so lets hipcc emit
+        // one ds_write_b128 per piece instead of two ds_write2_b32 (it cannot prove the alignment of a float index)
+        loff[i] = (col < NCOL) ? (v * VS + half * 4) / 4 : -1;
     }
     size_t zoff[4];
     bool zok[4];
@@ -140,10 +143,11 @@ __global__ __launch_bounds__(256, 2) void conv0_wz_mfma_kernel(
                 const f32x4 d1 = (hw0 || (in && zok[1])) ? stg[i][1] : zero;                    \
                 const f32x4 d2 = (hw0 || (in && zok[2])) ? stg[i][2] : zero;                    \
                 const f32x4 d3 = (hw0 || (in && zok[3])) ? stg[i][3] : zero;                    \
-                *reinterpret_cast<f32x4*>(tile + loff[i]) = d0 - d2;                           \
-                *reinterpret_cast<f32x4*>(tile + PLANE + loff[i]) = d1 + d2;                   \
-                *reinterpret_cast<f32x4*>(tile + 2 * PLANE + loff[i]) = d2 - d1;               \
-                *reinterpret_cast<f32x4*>(tile + 3 * PLANE + loff[i]) = d1 - d3;               \
+                f32x4* t4 = reinterpret_cast<f32x4*>(tile) + loff[i];                          \
+                t4[0] = d0 - d2;                                                               \
+                t4[PLANE / 4] = d1 + d2;                                                       \
+                t4[2 * (PLANE / 4)] = d2 - d1;                                                 \
+                t4[3 * (PLANE / 4)] = d1 - d3;                                                 \
             }                                                                                  \
         _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                        \
             if (tid + i * 256 < WPIECES) reinterpret_cast<f32x4*>(wlds)[tid + i * 256] = wst[i]; \

@@ -202,6 +202,237 @@ int launch_tc_dt(const void* feats_p, const float* rt, const float* dv, void* va
     return check_hip(hipGetLastError(), "warp_variance_tc launch");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second form of the tap-cache kernel (default).  The first form above spends its time in
+// instruction issue, not in memory: ~700 wave-instructions per (16 pixels x 4 planes x 1 depth)
+// because its three re-gather paths (shift left / shift right / full) all run whenever ANY lane of
+// the wave takes them -- with 16 pixels x 4 views per wave that is nearly every depth step -- plus
+// 64-bit address arithmetic for every gather and store.  This form has
+//   * ONE re-gather path per view: when the view's 2x2 texel cell changed (one packed key per
+//     view: o00 and the cell's (dy, dx) code), all four taps are gathered again -- more L1 traffic
+//     than the shift trick (still ~1/4 of the plain kernel's), a third of the instructions;
+//   * raw buffer loads / stores: the per-view base and the per-depth output plane travel in the
+//     scalar offset, so a gather costs one VALU (texel -> byte offset) and a store none;
+//   * the depth loop unrolled by two so that "this depth's / next depth's" sampling records swap
+//     roles without register copies.
+// Same taps, weights and fma nesting as the first form and the plain kernel: bit-identical output.
+// ---------------------------------------------------------------------------------------------
+struct SampK {
+    int key;                    // (o00 << 2) | (dy << 1) | dx : the view's clamped 2x2 cell
+    float w00, w01, w10, w11;   // bilinear weights (0 outside the image, NaN for non-finite coordinates)
+};
+
+__device__ __forceinline__ SampK make_samp_key(float qx, float qy, float qz, float tx, float ty, float tz, float d,
+                                               float sx, float sy, int h, int w) {
+    const Samp s = make_samp(qx, qy, qz, tx, ty, tz, d, sx, sy, h, w, 0, 0, w, h);
+    SampK k;
+    // o01 = o00 + dx, o10 = o00 + dy*w, o11 = o10 + dx with dx, dy in {0, 1} (clamped window)
+    k.key = (s.o00 << 2) | ((s.o10 != s.o00) ? 2 : 0) | (s.o01 - s.o00);
+    k.w00 = s.w00; k.w01 = s.w01; k.w10 = s.w10; k.w11 = s.w11;
+    return k;
+}
+
+template <int FDT>
+__device__ __forceinline__ void gather_tap_buf(f32x4& lo, f32x4& hi, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                               unsigned soff) {
+    if constexpr (FDT == MVS_F32) {
+        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u), (int)soff, 0));
+    } else {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        if constexpr (FDT == MVS_F16) {
+            const f16x8s hv = __builtin_bit_cast(f16x8s, raw);
+            lo = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            hi = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+        } else {
+            const bf16x8s hv = __builtin_bit_cast(bf16x8s, raw);
+            lo = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            hi = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+        }
+    }
+}
+
+template <int DT, int NTS>
+__device__ __forceinline__ void store_voxel_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff,
+                                                const f32x2 (&o)[4]) {
+    constexpr int aux = NTS ? 2 : 0;   // nt: the volume is written once and read by the next kernel from HBM
+    if constexpr (DT == MVS_F32) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
+                                                                  (f32x4){o[0].x, o[0].y, o[1].x, o[1].y}), rs, (int)voff, (int)soff, aux);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
+                                                                  (f32x4){o[2].x, o[2].y, o[3].x, o[3].y}), rs, (int)(voff + 16u), (int)soff, aux);
+    } else if constexpr (DT == MVS_F16) {
+        const f16x8s hv = {(_Float16)o[0].x, (_Float16)o[0].y, (_Float16)o[1].x, (_Float16)o[1].y,
+                           (_Float16)o[2].x, (_Float16)o[2].y, (_Float16)o[3].x, (_Float16)o[3].y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv),
+                                               rs, (int)voff, (int)soff, aux);
+    } else {
+        const bf16x8s hv = {(__bf16)o[0].x, (__bf16)o[0].y, (__bf16)o[1].x, (__bf16)o[1].y,
+                            (__bf16)o[2].x, (__bf16)o[2].y, (__bf16)o[3].x, (__bf16)o[3].y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv),
+                                               rs, (int)voff, (int)soff, aux);
+    }
+}
+
+template <int DT, int FDT, int NV, int NTS>
+__global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
+                                                                const float* __restrict__ rt,
+                                                                const float* __restrict__ dv,
+                                                                void* __restrict__ var, int N, int D, int h,
+                                                                int w, int slab) {
+    constexpr unsigned FES = FDT == MVS_F32 ? 4u : 2u;   // bytes per feature element
+    constexpr unsigned VES = DT == MVS_F32 ? 4u : 2u;    // bytes per volume element
+    const int pl = threadIdx.x & 3;
+    const int hw = h * w;
+    const int p_raw = blockIdx.x * kTcPixPerBlock + (threadIdx.x >> 2);
+    const bool live = p_raw < hw;
+    const int p = live ? p_raw : hw - 1;  // keep whole quads / waves converged for the DPP exchange
+    const int y = p / w, x = p - y * w;
+    const int d0 = blockIdx.y * slab, d1 = min(d0 + slab, D);
+    const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
+    const float fx = (float)x, fy = (float)y;
+    const float inv_n = 1.0f / (float)N;
+
+    // buffer descriptors: whole feature copy / whole volume (the launcher guarantees < 4 GiB each)
+    const unsigned fbytes = 4u * (unsigned)N * (unsigned)hw * 8u * FES;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(feats_p), (short)0, (int)fbytes, 0x00020000);
+    const unsigned vbytes = 4u * (unsigned)D * (unsigned)hw * 8u * VES;
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(var, (short)0, (int)vbytes, 0x00020000);
+    const unsigned plane_b = (unsigned)pl * (unsigned)N * (unsigned)hw * 8u * FES;   // this thread's channel plane
+    const unsigned view_b = (unsigned)hw * 8u * FES;                                  // bytes per view (scalar)
+    // out-of-range lanes of the last block store nothing: their byte offset lies beyond the volume
+    // (+16 for the second half must not wrap, and out-of-range lanes must stay out of range: their step is 0)
+    const unsigned dstep_v = live ? (unsigned)hw * 8u * VES : 0u;                     // bytes per depth plane
+    unsigned out_v = live ? (((unsigned)pl * (unsigned)D + (unsigned)d0) * (unsigned)hw + (unsigned)p) * 8u * VES
+                          : 0xFFFFFFE0u;
+
+    f32x4 r_lo, r_hi;
+    gather_tap_buf<FDT>(r_lo, r_hi, frs, plane_b + (unsigned)p * 8u * FES, 0u);
+    const f32x2 refp[4] = {{r_lo.x, r_lo.y}, {r_lo.z, r_lo.w}, {r_hi.x, r_hi.y}, {r_hi.z, r_hi.w}};
+
+    // the projection this lane evaluates for its quad: source view min(pl, NV-1) + 1
+    const int myv = pl < NV ? pl : NV - 1;
+    const float* r = rt + (size_t)myv * 12;
+    const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
+    const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
+    const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
+    const float tx = r[9], ty = r[10], tz = r[11];
+
+    f32x4 tap[NV][4][2];  // cached taps: [view][00,01,10,11][lo,hi]
+    int key[NV];          // cell key of the cached taps
+#pragma unroll
+    for (int v = 0; v < NV; ++v) key[v] = -1;
+
+    // one depth step with this depth's record `cur`; evaluates `nxt` for depth d+1 while the
+    // re-gathers are in flight
+    auto step = [&](const SampK& cur, SampK& nxt, int d) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int k = quad_bcast(cur.key, v);
+            if (k != key[v]) {   // quad-uniform: the four planes of a pixel share key and cache state
+                const unsigned o00 = (unsigned)k >> 2, dx = (unsigned)k & 1u, dyw = (k & 2) ? (unsigned)w : 0u;
+                const unsigned b00 = plane_b + o00 * (8u * FES);
+                const unsigned soff = (unsigned)(v + 1) * view_b;
+                gather_tap_buf<FDT>(tap[v][0][0], tap[v][0][1], frs, b00, soff);
+                gather_tap_buf<FDT>(tap[v][1][0], tap[v][1][1], frs, b00 + dx * (8u * FES), soff);
+                gather_tap_buf<FDT>(tap[v][2][0], tap[v][2][1], frs, b00 + dyw * (8u * FES), soff);
+                gather_tap_buf<FDT>(tap[v][3][0], tap[v][3][1], frs, b00 + (dyw + dx) * (8u * FES), soff);
+                key[v] = k;
+            }
+        }
+        nxt = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d + 1, D - 1)], sx, sy, h, w);
+        // blend + accumulate on channel pairs (v_pk_fma_f32 / v_pk_mul_f32)
+        f32x2 S[4], Q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S[j] = refp[j];
+            Q[j] = refp[j] * refp[j];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float w00 = quad_bcast(cur.w00, v), w01 = quad_bcast(cur.w01, v);
+            const float w10 = quad_bcast(cur.w10, v), w11 = quad_bcast(cur.w11, v);
+            const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int hh = j >> 1, q = (j & 1) * 2;
+                const f32x2 a = {tap[v][0][hh][q], tap[v][0][hh][q + 1]};
+                const f32x2 bb = {tap[v][1][hh][q], tap[v][1][hh][q + 1]};
+                const f32x2 c = {tap[v][2][hh][q], tap[v][2][hh][q + 1]};
+                const f32x2 e = {tap[v][3][hh][q], tap[v][3][hh][q + 1]};
+                // a*w00 + (b*w01 + (c*w10 + e*w11)) -- the plain kernel's nesting, per component
+                const f32x2 wv = __builtin_elementwise_fma(a, W00, __builtin_elementwise_fma(bb, W01,
+                                 __builtin_elementwise_fma(c, W10, e * W11)));
+                S[j] = S[j] + wv;
+                Q[j] = __builtin_elementwise_fma(wv, wv, Q[j]);
+            }
+        }
+        f32x2 o[4];
+        const f32x2 IN = {inv_n, inv_n};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // var = Q/N - (S/N)^2   (models/mvsnet.py:177)
+            const f32x2 m = S[j] * IN;
+            o[j] = __builtin_elementwise_fma(-m, m, Q[j] * IN);
+        }
+        // The depth plane travels in the VECTOR offset, not in the scalar offset field: a 16-byte
+        // buffer store whose soffset is an SGPR reads its data registers late, hipcc (ROCm 7.2) assumes
+        // that form has no store-data hazard and lets the next VALU instruction overwrite them -- on
+        // gfx950 the last lanes of each row then stored the NEXT value of the second dword.  With an
+        // immediate soffset the compiler inserts the wait state itself.
+        store_voxel_buf<DT, NTS>(vrs, out_v, 0u, o);
+        out_v += dstep_v;
+    };
+
+    SampK sa = make_samp_key(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w), sb;
+    int d = d0;
+    for (; d + 1 < d1; d += 2) {
+        step(sa, sb, d);
+        step(sb, sa, d + 1);
+    }
+    if (d < d1) step(sa, sb, d);
+}
+
+template <int DT, int FDT>
+int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
+                  int slab, bool nts, hipStream_t s) {
+    const dim3 grid((h * w + kTcPixPerBlock - 1) / kTcPixPerBlock, (D + slab - 1) / slab);
+#define MVS_TC2(NV)                                                                                          \
+    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); \
+    else warp_variance_tc2_kernel<DT, FDT, NV, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab);
+    switch (N - 1) {
+        case 1: MVS_TC2(1) break;
+        case 2: MVS_TC2(2) break;
+        case 3: MVS_TC2(3) break;
+        case 4: MVS_TC2(4) break;
+        default: return fail(MVS_ERR_BAD_SHAPE, "warp_variance_tc2: N = %d outside [2,5]", N);
+    }
+#undef MVS_TC2
+    return check_hip(hipGetLastError(), "warp_variance_tc2 launch");
+}
+
+// form 2 needs 32-bit byte offsets into the feature copy and the volume, and o00 << 2 in an int
+bool tc2_fits(int N, int D, int h, int w, int fes, int ves) {
+    const size_t hw = (size_t)h * w;
+    return 4 * (size_t)N * hw * 8 * fes < ((size_t)1 << 32) - 64 && 4 * (size_t)D * hw * 8 * ves < ((size_t)1 << 32) - 64 &&
+           hw < ((size_t)1 << 29);
+}
+
+int tc_form() {   // MVS_WARP_TC=1: the first form (A/B runs); default 2
+    static const int form = [] {
+        const char* e = getenv("MVS_WARP_TC");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return form;
+}
+
+bool tc_nt_stores() {   // MVS_WARP_NT=0: plain stores for the volume (default: non-temporal)
+    static const bool nt = [] {
+        const char* e = getenv("MVS_WARP_NT");
+        return !(e && e[0] == '0');
+    }();
+    return nt;
+}
+
 int tc_slab() {
     static const int slab = [] {
         const char* e = getenv("MVS_WARP_TC_SLAB");
@@ -217,6 +448,15 @@ int tc_slab() {
 int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
                             int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
+    if (tc_form() == 2 && tc2_fits(N, D, h, w, 4, dtype == MVS_F32 ? 4 : 2)) {
+        const bool nt = tc_nt_stores();
+        switch (dtype) {
+            case MVS_F32: return launch_tc2_dt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
+            case MVS_F16: return launch_tc2_dt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
+            case MVS_BF16: return launch_tc2_dt<MVS_BF16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
+            default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc: unknown dtype %d", dtype);
+        }
+    }
     switch (dtype) {
         case MVS_F32: return launch_tc_dt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
         case MVS_F16: return launch_tc_dt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
@@ -229,6 +469,14 @@ int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* 
 int launch_warp_variance_tc16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                               int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
+    if (tc_form() == 2 && tc2_fits(N, D, h, w, 2, 2)) {
+        const bool nt = tc_nt_stores();
+        switch (dtype) {
+            case MVS_F16: return launch_tc2_dt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, nt, s);
+            case MVS_BF16: return launch_tc2_dt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, nt, s);
+            default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc16 needs fp16 or bf16 (dtype %d)", dtype);
+        }
+    }
     switch (dtype) {
         case MVS_F16: return launch_tc_dt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, s);
         case MVS_BF16: return launch_tc_dt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, s);

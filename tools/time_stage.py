@@ -21,7 +21,9 @@ blob = _lib.pack_weights(synthetic.random_costreg_state(0)).to(dev)
 ws = _lib.alloc_workspace(N, 32, D, h, w, dev)
 rt = _lib.relative_proj(proj)
 var = _lib.warp_variance(feats, rt, dv, ws)
-layer = {"conv0": 0, "conv1": 1, "conv2": 2, "prob": 10}.get(what)
+layer = {"conv0": 0, "conv0z": 0, "conv1": 1, "conv2": 2, "prob": 10}.get(what)
+if what == "conv0z":   # all-zero input: same instruction stream, idle data paths (DVFS / power check)
+    var = torch.zeros_like(var)
 
 
 def run():
