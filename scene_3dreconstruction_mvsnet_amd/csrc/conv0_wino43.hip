@@ -1,0 +1,311 @@
+// conv0_wino43.hip -- conv0 (32 -> 8 channels, 68 % of the path's FLOPs; reference models/mvsnet.py:36,
+// block models/module.py:26-33) with Winograd F(4,3) along z on the 4x4x1 fp32 MFMA.
+//
+// conv0 is bound by the matrix pipe AND by the chip's power management (the same kernel runs 17 % faster
+// on an all-zero volume: the clock gives way under fp32 MFMA load), so the lever is fewer multiplications
+// and fewer bytes moved, not a tighter issue stream.  F(2,3) along z (conv0_winograd.hip) issues 2/3 of
+// the direct form's MFMAs and re-reads every input plane twice (4 halo planes per 2 output planes).
+// F(4,3) computes FOUR output planes from SIX transformed planes:
+//     U0 = 4 d0 - 5 d2 + d4            U5 = 4 d1 - 5 d3 + d5
+//     U1 = (d4 - 4 d2) + (d3 - 4 d1)   U2 = (d4 - 4 d2) - (d3 - 4 d1)
+//     U3 = (d4 - d2) + 2 (d3 - d1)     U4 = (d4 - d2) - 2 (d3 - d1)
+//     G0 = g0/4   G1 = -(g0+g1+g2)/6   G2 = -(g0-g1+g2)/6   G3 = g0/24 + g1/12 + g2/6
+//     G4 = g0/24 - g1/12 + g2/6        G5 = g2                        m_t = conv2d(U_t, G_t)
+//     y0 = m0 + m1 + m2 + m3 + m4      y1 = (m1 - m2) + 2 (m3 - m4)
+//     y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
+// i.e. 6 plane-convolutions per 4 output planes: 1/2 of the direct form's MFMAs (3/4 of F(2,3)'s) and
+// 6 halo planes per 4 outputs (3/4 of F(2,3)'s L2 -> LDS traffic).  As with F(2,3) the transformed
+// planes simply take the place of the halo planes in LDS; the weights are transformed on the host.
+//
+//   tile  : 4 (z) x 4 (y) x 32 (x) outputs; LDS: six transformed 6 x 34 halo planes of one 8-channel
+//           chunk (48-byte voxel stride, conflict-free ds_read_b128) + the chunk's weights = 72.6 KB,
+//           two blocks per CU
+//   block : 256 threads = 4 waves; the 12 work units (plane t, M-group of 2 rows x 32 x) are dealt three
+//           per wave, so every SIMD carries the same MFMA load; per (tap, half): 3 A reads + 4 broadcast
+//           B reads feed 24 MFMAs (v_mfma_f32_4x4x1_16b_f32, N = 4 channels: Cout = 8 is two exact tiles)
+//   K     : 4 chunks of 8 input channels (C8 planes), staged + transformed per chunk, chunk c+1's loads
+//           in flight during chunk c's MFMAs
+//   end   : the six m_t go through LDS once per tile; a thread then owns (position, 4 channels), forms
+//           y0..y3 (+bias, ReLU) and writes four 16-byte pieces
+// The sums are re-associated and the transform constants are not powers of two, so the result differs
+// from an fmaf chain by a few 1e-7 relative (tests bound it per layer against the oracle).
+#include "mvs_internal.h"
+#include "storage.h"
+
+namespace mvs {
+
+namespace c43 {
+constexpr int TZ = 4, TY = 4, TX = 32;
+constexpr int HY = TY + 2, HX = TX + 2;
+constexpr int NT_PLANES = 6;
+constexpr int VS = 12;                          // floats per voxel in LDS (8 data + 4 pad)
+constexpr int PLANE = HY * HX * VS;             // 2448 floats
+constexpr int TILE_FLOATS = NT_PLANES * PLANE;  // 58,752 B
+constexpr int NCOL = HY * HX * 2;               // z-columns of 16-byte pieces (y, x, half): 408
+constexpr int CPT = (NCOL + 255) / 256;         // 2
+constexpr int WPLANE = 9 * 2 * 2 * 16;          // weight floats per transformed plane per chunk
+constexpr int BW_FLOATS = NT_PLANES * WPLANE;   // per chunk [t][tap][half][nt][j][k]: 3456 floats
+constexpr int WPIECES = BW_FLOATS / 4;          // 864 16-byte pieces
+constexpr int WPT = (WPIECES + 255) / 256;      // 4
+constexpr int NPOS = TY * TX;                   // 128 (y, x) positions
+constexpr int EXS = 12;                         // floats per position in the exchange tile
+static_assert(NT_PLANES * NPOS * EXS <= TILE_FLOATS, "exchange tile must fit in the input tile");
+static_assert(PLANE % 4 == 0, "planes are addressed in 16-byte units");
+}  // namespace c43
+
+// PAR = wave parity: which of the wave's three units share a plane (even waves: units on planes
+// p, p, p+1; odd waves: p, p+1, p+1) -- a template so that the B-operand registers are picked at
+// compile time
+template <int PAR>
+__device__ __forceinline__ void c43_chunk_mfmas(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                const float* __restrict__ a2, const float* __restrict__ wA,
+                                                const float* __restrict__ wB, f32x4 (&acc)[3][2]) {
+    using namespace c43;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int koff = ((tap / 3) * HX + tap % 3) * VS;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + koff + half * 4);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + koff + half * 4);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(a2 + koff + half * 4);
+            const int wo = (tap * 2 + half) * 2 * 16;
+            const f32x4 bA0 = *reinterpret_cast<const f32x4*>(wA + wo);
+            const f32x4 bA1 = *reinterpret_cast<const f32x4*>(wA + wo + 16);
+            const f32x4 bB0 = *reinterpret_cast<const f32x4*>(wB + wo);
+            const f32x4 bB1 = *reinterpret_cast<const f32x4*>(wB + wo + 16);
+            const f32x4 m0 = PAR ? bB0 : bA0, m1 = PAR ? bB1 : bA1;   // unit 1's plane
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0[k], bA0[k], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1[k], m0[k], acc[1][0], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x2[k], bB0[k], acc[2][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0[k], bA1[k], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1[k], m1[k], acc[1][1], 0, 0, 0);
+                acc[2][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x2[k], bB1[k], acc[2][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
+    const void* __restrict__ x,      // [4][D][H][W][8] storage dtype DT
+    const float* __restrict__ bw,    // [4 chunks][6 t][9 taps][2 halves][2 nt][4 j][4 k]
+    const float* __restrict__ bias,  // [8]
+    void* __restrict__ y,            // [D][H][W][8] storage dtype DT
+    int D, int H, int W) {
+    using namespace c43;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + BW_FLOATS];
+    float* wlds = tile + TILE_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const size_t HW8 = (size_t)H * W * 8, V8 = (size_t)D * HW8;
+
+    // staging bookkeeping: a thread owns up to CPT z-columns (y, x, half) and stages all six planes of
+    // each.  Loads are unconditional (masked afterwards) so that the compiler keeps counted waits.
+    int goff[CPT], loff[CPT];
+    unsigned okxy = 0;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int col = tid + i * 256;
+        const int half = col & 1, v = col >> 1;
+        const int hx = v % HX, hy = v / HX;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = col < NCOL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (int)(((size_t)gy * W + gx) * 8 + half * 4) : 0;
+        okxy |= ok ? (1u << i) : 0u;
+        loff[i] = (col < NCOL) ? (v * VS + half * 4) / 4 : -1;   // in 16-byte units
+    }
+    size_t zoff[NT_PLANES];
+    bool zok[NT_PLANES];
+#pragma unroll
+    for (int q = 0; q < NT_PLANES; ++q) {
+        const int gz = z0 - 1 + q;
+        zok[q] = gz >= 0 && gz < D;
+        zoff[q] = zok[q] ? (size_t)gz * HW8 : 0;
+    }
+
+    // work units of this wave: u = 3 wave + i -> (plane u >> 1, M-group u & 1); lane -> (row, xl) of the
+    // M-group's 2 rows x 32 x
+    const int row = lane >> 5, xl = lane & 31;
+    const int u0 = 3 * wave;
+    const float* ab[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int u = u0 + i, pl = u >> 1, mg = u & 1;
+        ab[i] = tile + pl * PLANE + ((2 * mg + row) * HX + xl) * VS;
+    }
+    const int pA = u0 >> 1;   // the wave's two planes: pA, pA + 1
+    const float* wA = wlds + pA * WPLANE + (lane & 3) * 4;
+    const float* wB = wA + WPLANE;
+
+    f32x4 acc[3][2];  // [unit][nt]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 stg[CPT][NT_PLANES];
+    f32x4 wst[WPT];
+    // fp32 storage: raw buffer loads -- a piece outside the volume gets a byte offset beyond the
+    // buffer's range and the hardware returns zeros, so the transform needs no select instructions
+    unsigned boff[CPT][NT_PLANES];
+    if constexpr (DT == MVS_F32) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int q = 0; q < NT_PLANES; ++q)
+                boff[i][q] = (((okxy >> i) & 1u) && zok[q]) ? (unsigned)((zoff[q] + (size_t)goff[i]) * 4) : 0x80000000u;
+    }
+    auto load_chunk = [&](int c) {
+        const size_t plane = (size_t)c * V8;
+        if constexpr (DT == MVS_F32) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(static_cast<const float*>(x) + plane), (short)0, (int)(V8 * 4), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+#pragma unroll
+                for (int q = 0; q < NT_PLANES; ++q)
+                    stg[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff[i][q], 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+#pragma unroll
+                for (int q = 0; q < NT_PLANES; ++q) stg[i][q] = St<DT>::load4(x, plane + zoff[q] + goff[i]);
+        }
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(bw) + (size_t)c * WPIECES;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wst[i] = wsrc[min(tid + i * 256, WPIECES - 1)];
+    };
+    auto store_chunk = [&]() {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (loff[i] >= 0) {
+                const bool in = (okxy >> i) & 1u;
+                constexpr bool hw0 = DT == MVS_F32;  // zeros already delivered by the buffer loads
+                f32x4 d[NT_PLANES];
+#pragma unroll
+                for (int q = 0; q < NT_PLANES; ++q) d[q] = (hw0 || (in && zok[q])) ? stg[i][q] : zero;
+                const f32x4 t1 = d[4] - 4.0f * d[2], t2 = d[3] - 4.0f * d[1];
+                const f32x4 t3 = d[4] - d[2], t4 = 2.0f * (d[3] - d[1]);
+                f32x4* t4p = reinterpret_cast<f32x4*>(tile) + loff[i];
+                t4p[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+                t4p[PLANE / 4] = t1 + t2;
+                t4p[2 * (PLANE / 4)] = t1 - t2;
+                t4p[3 * (PLANE / 4)] = t3 + t4;
+                t4p[4 * (PLANE / 4)] = t3 - t4;
+                t4p[5 * (PLANE / 4)] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+            }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (tid + i * 256 < WPIECES) reinterpret_cast<f32x4*>(wlds)[tid + i * 256] = wst[i];
+    };
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c < 3) load_chunk(c + 1);
+        if (wave & 1) c43_chunk_mfmas<1>(ab[0], ab[1], ab[2], wA, wB, acc);
+        else c43_chunk_mfmas<0>(ab[0], ab[1], ab[2], wA, wB, acc);
+        if (c < 3) {
+            __syncthreads();  // every wave is done reading chunk c's planes and weights
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // exchange: D layout lane 4*blk + j, register i -> position 4*blk + i of the M-group, channel
+    // 4*nt + j.  ex[t][pos][channel], pos = 64 mg + (row * 32 + xl) = y * 32 + x of the tile.
+    __syncthreads();
+    {
+        const int blk = lane >> 2, j = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = u0 + i, pl = u >> 1, mg = u & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* e = tile + ((pl * NPOS + 64 * mg + 4 * blk + r) * EXS);
+                e[j] = acc[i][0][r];
+                e[4 + j] = acc[i][1][r];
+            }
+        }
+    }
+    __syncthreads();
+    const int pos = tid >> 1, ch = tid & 1;  // (y, x) of the 4 x 32 tile, channels 4 ch .. 4 ch + 3
+    const int gy = y0 + (pos >> 5), gx = x0 + (pos & 31);
+    if (gy >= H || gx >= W) return;
+    f32x4 M[NT_PLANES];
+#pragma unroll
+    for (int q = 0; q < NT_PLANES; ++q) M[q] = *reinterpret_cast<const f32x4*>(tile + (q * NPOS + pos) * EXS + ch * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + ch * 4);
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 s12 = M[1] + M[2], d12 = M[1] - M[2], s34 = M[3] + M[4], d34 = M[3] - M[4];
+    f32x4 o[TZ];
+    o[0] = (M[0] + s12) + s34;
+    o[1] = d12 + 2.0f * d34;
+    o[2] = s12 + 4.0f * s34;
+    o[3] = (d12 + 8.0f * d34) + M[5];
+#pragma unroll
+    for (int q = 0; q < TZ; ++q) {
+        if (z0 + q >= D) break;
+        const f32x4 v = __builtin_elementwise_max(o[q] + bv, zero);
+        St<DT>::store4(y, (((size_t)(z0 + q) * H + gy) * W + gx) * 8 + ch * 4, v);
+    }
+}
+
+template <int DT>
+static int run_conv0_w43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
+                         hipStream_t s) {
+    using namespace c43;
+    const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+    conv0_w43_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bw, bias, y, D, H, W);
+    return check_hip(hipGetLastError(), "conv0_w43_mfma launch");
+}
+
+int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
+                        int dtype, hipStream_t s) {
+    if ((size_t)D * H * W * 8 * 4 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "conv0_wino43: plane of %zu bytes exceeds 31-bit buffer offsets",
+                    (size_t)D * H * W * 8 * 4);
+    MVS_DISPATCH_DTYPE(dtype, (run_conv0_w43<DT>(x, y, bw, bias, D, H, W, s)))
+}
+
+// wfold [27][32][8] (tap = kz*9 + ky*3 + kx) -> bw [4 chunks][6 t][9][2 halves][2 nt][4 j][4 k] with the
+// z taps transformed by G of F(4,3) (double arithmetic, rounded once)
+void pack_conv0_wino43_weights(const float* wfold, float* bw) {
+    for (int c = 0; c < 4; ++c)
+        for (int t = 0; t < 6; ++t)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int half = 0; half < 2; ++half)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int j = 0; j < 4; ++j)
+                            for (int k = 0; k < 4; ++k) {
+                                const int ci = 8 * c + 4 * half + k, co = 4 * nt + j;
+                                const double g0 = wfold[((size_t)(0 * 9 + tap) * 32 + ci) * 8 + co];
+                                const double g1 = wfold[((size_t)(1 * 9 + tap) * 32 + ci) * 8 + co];
+                                const double g2 = wfold[((size_t)(2 * 9 + tap) * 32 + ci) * 8 + co];
+                                double g;
+                                switch (t) {
+                                    case 0: g = g0 / 4.0; break;
+                                    case 1: g = -(g0 + g1 + g2) / 6.0; break;
+                                    case 2: g = -(g0 - g1 + g2) / 6.0; break;
+                                    case 3: g = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+                                    case 4: g = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                                    default: g = g2; break;
+                                }
+                                bw[((((((size_t)c * 6 + t) * 9 + tap) * 2 + half) * 2 + nt) * 4 + j) * 4 + k] = (float)g;
+                            }
+}
+
+}  // namespace mvs

@@ -457,15 +457,20 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
                                    blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     if (layer == 0)
 {
-            // conv0: Winograd F(2,3) along z on the 4x4x1 MFMA (2/3 of the direct form's MFMAs) unless
-            // MVS_CONV0_WINO=0 or one of the direct variants is requested
-            static const bool wino = [] {
+            // conv0: Winograd along z on the 4x4x1 MFMA -- F(4,3) (1/2 of the direct form's MFMAs, default)
+            // or F(2,3) (2/3; MVS_CONV0_WINO=2) -- unless MVS_CONV0_WINO=0 or one of the direct variants
+            // is requested
+            static const int wino = [] {
                 const char* e = getenv("MVS_CONV0_WINO");
                 const char* p = getenv("MVS_CONV0_PAIR");
                 const char* w8 = getenv("MVS_CONV0_8W");
-                return !(e && e[0] == '0') && !(p && p[0] == '1') && !(w8 && w8[0] == '1');
+                if ((e && e[0] == '0') || (p && p[0] == '1') || (w8 && w8[0] == '1')) return 0;
+                return (e && e[0] == '2') ? 2 : 4;
             }();
-            if (wino && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31))   // else: direct kernel (64-bit offsets)
+            const bool fits = (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31);   // else: direct kernel (64-bit offsets)
+            if (wino == 4 && fits && Di % 4 == 0)
+                return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+            if (wino && fits)
                 return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
             return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
                                  dtype, s);

@@ -45,6 +45,7 @@ struct BlobLayout {
     size_t h16_off[2][10];         // 16-bit MFMA panels of layers 0..9 for MVS_F16 ([0]) / MVS_BF16 ([1])
     size_t c0w_off;                // conv0 Winograd-z panel [4][4][9][2][2][4][4] (conv0_winograd.hip)
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv0_winograd.hip)
+    size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv0_wino43.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -84,6 +85,8 @@ inline BlobLayout blob_layout() {
         L.wz_off[l] = off;
         off += (size_t)(kLayers[l].cin / 8) * 4 * (kLayers[l].cout / 16) * 5 * 64 * 4;
     }
+    L.c0w43_off = off;
+    off += (size_t)4 * 6 * 9 * 2 * 2 * 4 * 4;
     L.total_floats = off;
     return L;
 }
@@ -207,6 +210,9 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
 int launch_conv0_winograd(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                           int dtype, hipStream_t s);
 void pack_conv0_winograd_weights(const float* wfold, float* bw);
+int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
+                        int dtype, hipStream_t s);
+void pack_conv0_wino43_weights(const float* wfold, float* bw);
 int launch_convwz_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int D, int H,
                        int W, int dtype, hipStream_t s);
 void pack_convwz_weights(const float* wfold, int cin, int cout, float* bp);
