@@ -203,18 +203,27 @@ int launch_tc_dt(const void* feats_p, const float* rt, const float* dv, void* va
 }
 
 // ---------------------------------------------------------------------------------------------
-// Second form of the tap-cache kernel (default).  The first form above spends its time in
-// instruction issue, not in memory: ~700 wave-instructions per (16 pixels x 4 planes x 1 depth)
-// because its three re-gather paths (shift left / shift right / full) all run whenever ANY lane of
-// the wave takes them -- with 16 pixels x 4 views per wave that is nearly every depth step -- plus
-// 64-bit address arithmetic for every gather and store.  This form has
-//   * ONE re-gather path per view: when the view's 2x2 texel cell changed (one packed key per
-//     view: o00 and the cell's (dy, dx) code), all four taps are gathered again -- more L1 traffic
-//     than the shift trick (still ~1/4 of the plain kernel's), a third of the instructions;
-//   * raw buffer loads / stores: the per-view base and the per-depth output plane travel in the
-//     scalar offset, so a gather costs one VALU (texel -> byte offset) and a store none;
-//   * the depth loop unrolled by two so that "this depth's / next depth's" sampling records swap
-//     roles without register copies.
+// Second form of the tap-cache kernel (default), templated on the channels per thread CPT.
+//
+// What rocprofv3 showed for the first form (profiles/r02_warp_pmc.md): only ~240 VALU and ~5 load
+// instructions are executed per wave and depth step -- the re-gather branches are skipped at wave
+// level three times out of four -- yet a step takes ~3,300 cycles, 53 % of them parked in
+// s_waitcnt.  vmcnt counts loads and stores together in issue order, so every wait for re-gathered
+// taps also waits for all older stores of the wave, i.e. for the HBM write latency; with 250 VGPRs
+// only 8 waves per CU are resident, each with two depth steps of stores in flight: 32 KB per CU,
+// which at ~3.6 us store latency is the 2.3 TB/s the kernel ran at.  The kernel is bound by the
+// bytes it can keep in flight.  Hence:
+//   * CPT = 4 channels per thread (8 lanes per pixel): the tap cache is 16 VGPRs per view instead of
+//     32, the kernel fits 128 VGPRs and 16 waves per CU are resident (twice the stores in flight,
+//     twice the VALU issue rate -- one wave issues at most one VALU per ~5 cycles on gfx950);
+//   * ONE re-gather path per view (packed key o00 | dy | dx; all four taps are gathered again when
+//     the 2x2 cell changed) instead of three; the taps of depth d+1 are requested right after depth
+//     d's blend has read the cache and BEFORE depth d's stores, so the wait of the next step leaves
+//     the two youngest stores in flight;
+//   * raw buffer loads / stores: the per-view base travels in the scalar offset, a gather costs one
+//     VALU (texel -> byte offset); out-of-range lanes of the last block fall outside the descriptor;
+//   * three sampling records rotate through the depth loop (this depth's weights, next depth's cell
+//     key, the projection being evaluated for d+2): no register copies.
 // Same taps, weights and fma nesting as the first form and the plain kernel: bit-identical output.
 // ---------------------------------------------------------------------------------------------
 struct SampK {
@@ -232,49 +241,78 @@ __device__ __forceinline__ SampK make_samp_key(float qx, float qy, float qz, flo
     return k;
 }
 
-template <int FDT>
-__device__ __forceinline__ void gather_tap_buf(f32x4& lo, f32x4& hi, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+
+// CPT consecutive channels of one texel -> CPT/4 f32x4 (16-bit features are widened once here)
+template <int FDT, int CPT>
+__device__ __forceinline__ void gather_tap_buf(f32x4 (&t)[CPT / 4], __amdgpu_buffer_rsrc_t rs, unsigned voff,
                                                unsigned soff) {
     if constexpr (FDT == MVS_F32) {
-        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
-        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u), (int)soff, 0));
-    } else {
+#pragma unroll
+        for (int i = 0; i < CPT / 4; ++i)
+            t[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u * i), (int)soff, 0));
+    } else if constexpr (CPT == 8) {
         const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
         if constexpr (FDT == MVS_F16) {
             const f16x8s hv = __builtin_bit_cast(f16x8s, raw);
-            lo = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-            hi = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+            t[0] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            t[1] = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
         } else {
             const bf16x8s hv = __builtin_bit_cast(bf16x8s, raw);
-            lo = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-            hi = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+            t[0] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            t[1] = (f32x4){(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+        }
+    } else {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+        if constexpr (FDT == MVS_F16) {
+            const f16x4s hv = __builtin_bit_cast(f16x4s, raw);
+            t[0] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {
+            const bf16x4s hv = __builtin_bit_cast(bf16x4s, raw);
+            t[0] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
         }
     }
 }
 
-template <int DT, int NTS>
-__device__ __forceinline__ void store_voxel_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff,
-                                                const f32x2 (&o)[4]) {
-    constexpr int aux = NTS ? 2 : 0;   // nt: the volume is written once and read by the next kernel from HBM
+// CPT consecutive channels of one voxel.  The scalar offset field stays an immediate 0 on purpose: a
+// 16-byte buffer store whose soffset is an SGPR reads its data registers late, hipcc (ROCm 7.2) assumes
+// that form has no store-data hazard and lets the next VALU instruction overwrite them -- on gfx950
+// the last lanes of each row then stored the NEXT value of the second dword.  With an immediate
+// soffset the compiler inserts the wait state itself.
+template <int DT, int CPT, int NTS>
+__device__ __forceinline__ void store_voxel_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, const f32x2 (&o)[CPT / 2]) {
+    constexpr int aux = NTS ? 2 : 0;   // nt: measured slower (0.253 vs 0.233 ms), kept as MVS_WARP_NT=1
     if constexpr (DT == MVS_F32) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
-                                                                  (f32x4){o[0].x, o[0].y, o[1].x, o[1].y}), rs, (int)voff, (int)soff, aux);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
-                                                                  (f32x4){o[2].x, o[2].y, o[3].x, o[3].y}), rs, (int)(voff + 16u), (int)soff, aux);
-    } else if constexpr (DT == MVS_F16) {
-        const f16x8s hv = {(_Float16)o[0].x, (_Float16)o[0].y, (_Float16)o[1].x, (_Float16)o[1].y,
-                           (_Float16)o[2].x, (_Float16)o[2].y, (_Float16)o[3].x, (_Float16)o[3].y};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv),
-                                               rs, (int)voff, (int)soff, aux);
+#pragma unroll
+        for (int i = 0; i < CPT / 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, (f32x4){o[2 * i].x, o[2 * i].y, o[2 * i + 1].x, o[2 * i + 1].y}), rs,
+                (int)(voff + 16u * i), 0, aux);
+    } else if constexpr (CPT == 8) {
+        if constexpr (DT == MVS_F16) {
+            const f16x8s hv = {(_Float16)o[0].x, (_Float16)o[0].y, (_Float16)o[1].x, (_Float16)o[1].y,
+                               (_Float16)o[2].x, (_Float16)o[2].y, (_Float16)o[3].x, (_Float16)o[3].y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rs, (int)voff, 0, aux);
+        } else {
+            const bf16x8s hv = {(__bf16)o[0].x, (__bf16)o[0].y, (__bf16)o[1].x, (__bf16)o[1].y,
+                                (__bf16)o[2].x, (__bf16)o[2].y, (__bf16)o[3].x, (__bf16)o[3].y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rs, (int)voff, 0, aux);
+        }
     } else {
-        const bf16x8s hv = {(__bf16)o[0].x, (__bf16)o[0].y, (__bf16)o[1].x, (__bf16)o[1].y,
-                            (__bf16)o[2].x, (__bf16)o[2].y, (__bf16)o[3].x, (__bf16)o[3].y};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, hv),
-                                               rs, (int)voff, (int)soff, aux);
+        if constexpr (DT == MVS_F16) {
+            const f16x4s hv = {(_Float16)o[0].x, (_Float16)o[0].y, (_Float16)o[1].x, (_Float16)o[1].y};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, (int)voff, 0, aux);
+        } else {
+            const bf16x4s hv = {(__bf16)o[0].x, (__bf16)o[0].y, (__bf16)o[1].x, (__bf16)o[1].y};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, (int)voff, 0, aux);
+        }
     }
 }
 
-template <int DT, int FDT, int NV, int NTS>
+template <int DT, int FDT, int NV, int CPT, int NTS>
 __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
                                                                 const float* __restrict__ rt,
                                                                 const float* __restrict__ dv,
@@ -282,9 +320,12 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
                                                                 int w, int slab) {
     constexpr unsigned FES = FDT == MVS_F32 ? 4u : 2u;   // bytes per feature element
     constexpr unsigned VES = DT == MVS_F32 ? 4u : 2u;    // bytes per volume element
-    const int pl = threadIdx.x & 3;
+    constexpr int LPP = 32 / CPT;                        // lanes per pixel: 4 (CPT = 8) or 8 (CPT = 4)
+    constexpr int NH = CPT / 4, NP = CPT / 2;            // f32x4 / channel pairs per tap
+    const int sub = threadIdx.x & (LPP - 1);             // this thread's channels: sub * CPT .. + CPT - 1
+    const int pl = (sub * CPT) >> 3, cin = (sub * CPT) & 7;   // C8 plane and first channel inside it
     const int hw = h * w;
-    const int p_raw = blockIdx.x * kTcPixPerBlock + (threadIdx.x >> 2);
+    const int p_raw = blockIdx.x * (256 / LPP) + (threadIdx.x / LPP);
     const bool live = p_raw < hw;
     const int p = live ? p_raw : hw - 1;  // keep whole quads / waves converged for the DPP exchange
     const int y = p / w, x = p - y * w;
@@ -298,53 +339,58 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(feats_p), (short)0, (int)fbytes, 0x00020000);
     const unsigned vbytes = 4u * (unsigned)D * (unsigned)hw * 8u * VES;
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(var, (short)0, (int)vbytes, 0x00020000);
-    const unsigned plane_b = (unsigned)pl * (unsigned)N * (unsigned)hw * 8u * FES;   // this thread's channel plane
+    const unsigned plane_b = ((unsigned)pl * (unsigned)N * (unsigned)hw * 8u + (unsigned)cin) * FES;   // this thread's channels of view 0, texel 0
     const unsigned view_b = (unsigned)hw * 8u * FES;                                  // bytes per view (scalar)
-    // out-of-range lanes of the last block store nothing: their byte offset lies beyond the volume
-    // (+16 for the second half must not wrap, and out-of-range lanes must stay out of range: their step is 0)
-    const unsigned dstep_v = live ? (unsigned)hw * 8u * VES : 0u;                     // bytes per depth plane
-    unsigned out_v = live ? (((unsigned)pl * (unsigned)D + (unsigned)d0) * (unsigned)hw + (unsigned)p) * 8u * VES
+    // the depth plane advances in the vector offset (see store_voxel_buf); out-of-range lanes of the last
+    // block stay beyond the descriptor's range: offset 0xFFFFFFE0 (+16 must not wrap), step 0
+    const unsigned dstep_v = live ? (unsigned)hw * 8u * VES : 0u;
+    unsigned out_v = live ? ((((unsigned)pl * (unsigned)D + (unsigned)d0) * (unsigned)hw + (unsigned)p) * 8u + (unsigned)cin) * VES
                           : 0xFFFFFFE0u;
 
-    f32x4 r_lo, r_hi;
-    gather_tap_buf<FDT>(r_lo, r_hi, frs, plane_b + (unsigned)p * 8u * FES, 0u);
-    const f32x2 refp[4] = {{r_lo.x, r_lo.y}, {r_lo.z, r_lo.w}, {r_hi.x, r_hi.y}, {r_hi.z, r_hi.w}};
+    f32x4 rf[NH];
+    gather_tap_buf<FDT, CPT>(rf, frs, plane_b + (unsigned)p * 8u * FES, 0u);
+    f32x2 refp[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) refp[j] = (f32x2){rf[j >> 1][(j & 1) * 2], rf[j >> 1][(j & 1) * 2 + 1]};
 
-    // the projection this lane evaluates for its quad: source view min(pl, NV-1) + 1
-    const int myv = pl < NV ? pl : NV - 1;
+    // the projection this lane evaluates for its quad: source view min(lane & 3, NV-1) + 1 (with 8 lanes
+    // per pixel both quads of a pixel evaluate all views: same instruction stream, no cross-quad traffic)
+    const int myv = (sub & 3) < NV ? (sub & 3) : NV - 1;
     const float* r = rt + (size_t)myv * 12;
     const float qx = fmaf(r[0], fx, fmaf(r[1], fy, r[2]));
     const float qy = fmaf(r[3], fx, fmaf(r[4], fy, r[5]));
     const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
     const float tx = r[9], ty = r[10], tz = r[11];
 
-    f32x4 tap[NV][4][2];  // cached taps: [view][00,01,10,11][lo,hi]
-    int key[NV];          // cell key of the cached taps
+    f32x4 tap[NV][4][NH];  // cached taps: [view][00,01,10,11][16-byte piece]
+    int key[NV];           // cell key of the cached taps
 #pragma unroll
     for (int v = 0; v < NV; ++v) key[v] = -1;
 
-    // one depth step with this depth's record `cur`; evaluates `nxt` for depth d+1 while the
-    // re-gathers are in flight
-    auto step = [&](const SampK& cur, SampK& nxt, int d) {
+    // (re-)gather the taps of every view whose 2x2 cell differs from the cached one
+    auto regather = [&](const SampK& rec) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int k = quad_bcast(cur.key, v);
-            if (k != key[v]) {   // quad-uniform: the four planes of a pixel share key and cache state
+            const int k = quad_bcast(rec.key, v);
+            if (k != key[v]) {   // uniform over the lanes of a pixel: they share key and cache state
                 const unsigned o00 = (unsigned)k >> 2, dx = (unsigned)k & 1u, dyw = (k & 2) ? (unsigned)w : 0u;
                 const unsigned b00 = plane_b + o00 * (8u * FES);
                 const unsigned soff = (unsigned)(v + 1) * view_b;
-                gather_tap_buf<FDT>(tap[v][0][0], tap[v][0][1], frs, b00, soff);
-                gather_tap_buf<FDT>(tap[v][1][0], tap[v][1][1], frs, b00 + dx * (8u * FES), soff);
-                gather_tap_buf<FDT>(tap[v][2][0], tap[v][2][1], frs, b00 + dyw * (8u * FES), soff);
-                gather_tap_buf<FDT>(tap[v][3][0], tap[v][3][1], frs, b00 + (dyw + dx) * (8u * FES), soff);
+                gather_tap_buf<FDT, CPT>(tap[v][0], frs, b00, soff);
+                gather_tap_buf<FDT, CPT>(tap[v][1], frs, b00 + dx * (8u * FES), soff);
+                gather_tap_buf<FDT, CPT>(tap[v][2], frs, b00 + dyw * (8u * FES), soff);
+                gather_tap_buf<FDT, CPT>(tap[v][3], frs, b00 + (dyw + dx) * (8u * FES), soff);
                 key[v] = k;
             }
         }
-        nxt = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d + 1, D - 1)], sx, sy, h, w);
+    };
+
+    // one depth step: blend with `cur`'s weights, request `nxt`'s taps, variance + stores, evaluate `nn`
+    auto step = [&](const SampK& cur, const SampK& nxt, SampK& nn, int d) {
         // blend + accumulate on channel pairs (v_pk_fma_f32 / v_pk_mul_f32)
-        f32x2 S[4], Q[4];
+        f32x2 S[NP], Q[NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NP; ++j) {
             S[j] = refp[j];
             Q[j] = refp[j] * refp[j];
         }
@@ -354,7 +400,7 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
             const float w10 = quad_bcast(cur.w10, v), w11 = quad_bcast(cur.w11, v);
             const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NP; ++j) {
                 const int hh = j >> 1, q = (j & 1) * 2;
                 const f32x2 a = {tap[v][0][hh][q], tap[v][0][hh][q + 1]};
                 const f32x2 bb = {tap[v][1][hh][q], tap[v][1][hh][q + 1]};
@@ -367,38 +413,46 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
                 Q[j] = __builtin_elementwise_fma(wv, wv, Q[j]);
             }
         }
-        f32x2 o[4];
+        // pin the sums here: without it hipcc sinks the blend below the re-gather branches, keeps the
+        // old taps alive across them and needs a second set of tap registers (378 VGPRs + AGPRs)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(S[j]), "+v"(Q[j]));
+        if (d + 1 < d1) regather(nxt);   // wave-uniform: the slab's last step has no successor
+        f32x2 o[NP];
         const f32x2 IN = {inv_n, inv_n};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // var = Q/N - (S/N)^2   (models/mvsnet.py:177)
+        for (int j = 0; j < NP; ++j) {   // var = Q/N - (S/N)^2   (models/mvsnet.py:177)
             const f32x2 m = S[j] * IN;
             o[j] = __builtin_elementwise_fma(-m, m, Q[j] * IN);
         }
-        // The depth plane travels in the VECTOR offset, not in the scalar offset field: a 16-byte
-        // buffer store whose soffset is an SGPR reads its data registers late, hipcc (ROCm 7.2) assumes
-        // that form has no store-data hazard and lets the next VALU instruction overwrite them -- on
-        // gfx950 the last lanes of each row then stored the NEXT value of the second dword.  With an
-        // immediate soffset the compiler inserts the wait state itself.
-        store_voxel_buf<DT, NTS>(vrs, out_v, 0u, o);
+        store_voxel_buf<DT, CPT, NTS>(vrs, out_v, o);
         out_v += dstep_v;
+        nn = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d + 2, D - 1)], sx, sy, h, w);
     };
 
-    SampK sa = make_samp_key(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w), sb;
+    SampK sa = make_samp_key(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w);
+    SampK sb = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d0 + 1, D - 1)], sx, sy, h, w), sc;
+    regather(sa);
     int d = d0;
-    for (; d + 1 < d1; d += 2) {
-        step(sa, sb, d);
-        step(sb, sa, d + 1);
+    for (; d + 2 < d1; d += 3) {   // three records rotate: no register copies
+        step(sa, sb, sc, d);
+        step(sb, sc, sa, d + 1);
+        step(sc, sa, sb, d + 2);
     }
-    if (d < d1) step(sa, sb, d);
+    if (d < d1) {
+        step(sa, sb, sc, d);
+        if (d + 1 < d1) step(sb, sc, sa, d + 1);
+    }
 }
 
-template <int DT, int FDT>
+template <int DT, int FDT, int CPT>
 int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
                   int slab, bool nts, hipStream_t s) {
-    const dim3 grid((h * w + kTcPixPerBlock - 1) / kTcPixPerBlock, (D + slab - 1) / slab);
-#define MVS_TC2(NV)                                                                                          \
-    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); \
-    else warp_variance_tc2_kernel<DT, FDT, NV, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab);
+    constexpr int pix = 256 / (32 / CPT);
+    const dim3 grid((h * w + pix - 1) / pix, (D + slab - 1) / slab);
+#define MVS_TC2(NV)                                                                                               \
+    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); \
+    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab);
     switch (N - 1) {
         case 1: MVS_TC2(1) break;
         case 2: MVS_TC2(2) break;
@@ -425,12 +479,28 @@ int tc_form() {   // MVS_WARP_TC=1: the first form (A/B runs); default 2
     return form;
 }
 
-bool tc_nt_stores() {   // MVS_WARP_NT=0: plain stores for the volume (default: non-temporal)
+int tc_cpt() {   // MVS_WARP_CPT=8: 8 channels per thread (4 lanes per pixel, 8 waves per CU); default 4
+    static const int cpt = [] {
+        const char* e = getenv("MVS_WARP_CPT");
+        return (e && e[0] == '8') ? 8 : 4;
+    }();
+    return cpt;
+}
+
+bool tc_nt_stores() {   // MVS_WARP_NT=1: non-temporal stores for the volume (measured slower)
     static const bool nt = [] {
         const char* e = getenv("MVS_WARP_NT");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     return nt;
+}
+
+template <int DT, int FDT>
+int launch_tc2_cpt(const void* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
+                   int slab, hipStream_t s) {
+    const bool nt = tc_nt_stores();
+    if (tc_cpt() == 8) return launch_tc2_dt<DT, FDT, 8>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
+    return launch_tc2_dt<DT, FDT, 4>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
 }
 
 int tc_slab() {
@@ -449,11 +519,10 @@ int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* 
                             int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
     if (tc_form() == 2 && tc2_fits(N, D, h, w, 4, dtype == MVS_F32 ? 4 : 2)) {
-        const bool nt = tc_nt_stores();
         switch (dtype) {
-            case MVS_F32: return launch_tc2_dt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
-            case MVS_F16: return launch_tc2_dt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
-            case MVS_BF16: return launch_tc2_dt<MVS_BF16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, nt, s);
+            case MVS_F32: return launch_tc2_cpt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
+            case MVS_F16: return launch_tc2_cpt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
+            case MVS_BF16: return launch_tc2_cpt<MVS_BF16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
             default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc: unknown dtype %d", dtype);
         }
     }
@@ -470,10 +539,9 @@ int launch_warp_variance_tc16(const void* feats16, const float* rt, const float*
                               int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
     if (tc_form() == 2 && tc2_fits(N, D, h, w, 2, 2)) {
-        const bool nt = tc_nt_stores();
         switch (dtype) {
-            case MVS_F16: return launch_tc2_dt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, nt, s);
-            case MVS_BF16: return launch_tc2_dt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, nt, s);
+            case MVS_F16: return launch_tc2_cpt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, s);
+            case MVS_BF16: return launch_tc2_cpt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, s);
             default: return fail(MVS_ERR_BAD_DTYPE, "warp_variance_tc16 needs fp16 or bf16 (dtype %d)", dtype);
         }
     }
