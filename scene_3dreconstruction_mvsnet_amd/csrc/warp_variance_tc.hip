@@ -225,6 +225,11 @@ int launch_tc_dt(const void* feats_p, const float* rt, const float* dv, void* va
 //   * three sampling records rotate through the depth loop (this depth's weights, next depth's cell
 //     key, the projection being evaluated for d+2): no register copies.
 // Same taps, weights and fma nesting as the first form and the plain kernel: bit-identical output.
+// Measured at cfg2: 0.2345 ms (first form) -> 0.157 ms.  Tried on top and dropped: distributing the
+// sampling records through a per-wave LDS ring with one projection per two depth steps (~125 instead
+// of 155 VALU per step: 0.159 ms, no gain); non-temporal stores (slower); depth slabs of 48 / 96 (the
+// 5,120 blocks of slab 24 are exactly five rounds of the 1,024 resident blocks).  Ablations: without
+// the stores -0.055 ms, without re-gathers -0.050 ms: the three parts do not overlap yet.
 // ---------------------------------------------------------------------------------------------
 struct SampK {
     int key;                    // (o00 << 2) | (dy << 1) | dx : the view's clamped 2x2 cell
@@ -518,7 +523,7 @@ int tc_slab() {
 int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
                             int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
-    if (tc_form() == 2 && tc2_fits(N, D, h, w, 4, dtype == MVS_F32 ? 4 : 2)) {
+    if (tc_form() >= 2 && tc2_fits(N, D, h, w, 4, dtype == MVS_F32 ? 4 : 2)) {
         switch (dtype) {
             case MVS_F32: return launch_tc2_cpt<MVS_F32, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
             case MVS_F16: return launch_tc2_cpt<MVS_F16, MVS_F32>(feats_p, rt, dv, var, N, D, h, w, slab, s);
@@ -538,7 +543,7 @@ int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* 
 int launch_warp_variance_tc16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                               int h, int w, int dtype, hipStream_t s) {
     const int slab = tc_slab();
-    if (tc_form() == 2 && tc2_fits(N, D, h, w, 2, 2)) {
+    if (tc_form() >= 2 && tc2_fits(N, D, h, w, 2, 2)) {
         switch (dtype) {
             case MVS_F16: return launch_tc2_cpt<MVS_F16, MVS_F16>(feats16, rt, dv, var, N, D, h, w, slab, s);
             case MVS_BF16: return launch_tc2_cpt<MVS_BF16, MVS_BF16>(feats16, rt, dv, var, N, D, h, w, slab, s);

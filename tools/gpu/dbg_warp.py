@@ -35,7 +35,7 @@ def main():
     from oracle import oracle as orc
     from scene_3dreconstruction_mvsnet_amd import synthetic
     csrc = os.path.join(REPO, "scene_3dreconstruction_mvsnet_amd", "csrc")
-    envs = {"form1": {"MVS_WARP_TC": "1"}, "form2_cpt4": {}, "form2_cpt8": {"MVS_WARP_CPT": "8"}}
+    envs = {"form1": {"MVS_WARP_TC": "1"}, "form2_cpt4": {"MVS_WARP_TC": "2"}, "form3": {}}
     for v in (1, 2, 4, 8):
         lib = os.path.join(csrc, f"libmvs_hip_dbg{v}.so")
         if os.path.exists(lib):
