@@ -76,8 +76,9 @@ def parse_args(argv=None):
                          "f32 for cfg1/cfg2, bf16 for cfg3, f16 for cfg5 as BASELINE.json names them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (from images) figure")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams to round-robin independent maps over (each has its own workspace)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams to round-robin independent maps over (each has its own workspace); two maps "
+                         "in flight fill the launch gaps and the tails of the small U-Net layers (+6 %% over 1)")
     ap.add_argument("--fused-conv0", action="store_true",
                     help="staged pass: use the fused mvs_warp_conv0 kernel (variance volume never "
                          "materialised) instead of separate warp+variance and conv0 kernels")
@@ -306,6 +307,10 @@ def main(argv=None):
                 ent["frac"] = round(floor_ms / ms, 3)
             stages[name] = ent
     roofline = None
+    # which conv0 kernel the library picks (csrc/conv3d_direct.hip): F(4,3) unless told otherwise
+    wino = "0" if (os.environ.get("MVS_CONV0_WINO") == "0" or os.environ.get("MVS_CONV0_PAIR") == "1"
+                   or os.environ.get("MVS_CONV0_8W") == "1") else \
+        ("2" if os.environ.get("MVS_CONV0_WINO") == "2" or D % 4 else "4")
     if stages:
         dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
         c, ms = costs[dom], stages[dom]["ms"]
@@ -318,13 +323,13 @@ def main(argv=None):
                         "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
                         "algorithmic_bytes": c["bytes"]}
-            if dom == "conv0" and storage == "f32" and os.environ.get("MVS_CONV0_WINO", "1") != "0" \
-                    and os.environ.get("MVS_CONV0_PAIR") != "1" and os.environ.get("MVS_CONV0_8W") != "1":
-                roofline["note"] = ("conv0 runs Winograd F(2,3) along z on the fp32 4x4x1 MFMA: it issues 2/3 of "
-                                    "the algorithmic multiply-adds (36.2 of 54.4 GFLOP); `achieved` is the "
-                                    "ALGORITHMIC flops / time as SURVEY 8 d3 defines it, the executed-MFMA "
-                                    "rate is 2/3 of that")
-                roofline["executed_flops"] = c["flops"] * 2 // 3
+            if dom == "conv0" and storage == "f32" and wino in ("2", "4"):
+                num, den, form = (1, 2, "F(4,3)") if wino == "4" else (2, 3, "F(2,3)")
+                roofline["note"] = (f"conv0 runs Winograd {form} along z on the fp32 4x4x1 MFMA: it issues {num}/{den} "
+                                    "of the algorithmic multiply-adds; `achieved` is the ALGORITHMIC flops / time as "
+                                    f"SURVEY 8 d3 defines it (it can exceed the MFMA peak), the executed-MFMA rate is "
+                                    f"{num}/{den} of that")
+                roofline["executed_flops"] = c["flops"] * num // den
         else:
             ach = c["bytes"] / ms / 1e6
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
@@ -335,13 +340,18 @@ def main(argv=None):
     # FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction; profiles/r01_traffic.json)
     if roofline is not None and args.config == "cfg2":
         try:
-            with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            import glob
+            newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]
+            with open(newest) as f:
                 prof = json.load(f)["kernels"]
-            kname = {"conv0": ("mvs::conv0_wz_mfma_kernel<0>" if "note" in roofline else "mvs::conv0_4x4_mfma_kernel<0>"), "warp_variance": "mvs::warp_variance_tc_kernel<0, 0, 4>"}
-            ent = prof.get(kname.get(roofline["kernel"], ""))
+            want = {"conv0": "conv0_w43_mfma_kernel<0>" if wino == "4" else
+                             ("conv0_wz_mfma_kernel<0>" if wino == "2" else "conv0_4x4_mfma_kernel<0>"),
+                    "warp_variance": "warp_variance_tc2_kernel<0, 0, 4, 4, 0>"}.get(roofline["kernel"], "?")
+            ent = next((v for k, v in prof.items() if k.endswith(want)), None)
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
-                roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 PMC, per launch)"
+                roofline["traffic_source"] = (f"profiles/{os.path.basename(newest)} (rocprofv3 --pmc FETCH_SIZE / "
+                                              "WRITE_SIZE passes of the same kernels, per launch; FETCH x2 gfx950 correction)")
         except (OSError, KeyError, ValueError):
             pass
 

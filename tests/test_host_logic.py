@@ -163,6 +163,16 @@ def test_pack_weights_folds_bn_and_relayouts():
             want = Gl[t][tap, 8 * c + 4 * (g & 1) + j4, 16 * n + col] if tap < 9 else 0.0
             np.testing.assert_allclose(panel[c, t, n, ks, lane, j4], want, rtol=1e-6, atol=1e-9)
         off += nch * 4 * nt * 5 * 256
+    # conv0 Winograd F(4,3)-z panel [4 chunks][6 t][9 taps][2 halves][2 nt][4 j][4 k] (conv0_wino43.hip)
+    w43 = blob[off:off + 4 * 6 * 9 * 2 * 2 * 4 * 4].reshape(4, 6, 9, 2, 2, 4, 4)
+    g = blob[:27 * 32 * 8].reshape(3, 9, 32, 8).astype(np.float64)
+    G43 = [g[0] / 4, -(g[0] + g[1] + g[2]) / 6, -(g[0] - g[1] + g[2]) / 6,
+           g[0] / 24 + g[1] / 12 + g[2] / 6, g[0] / 24 - g[1] / 12 + g[2] / 6, g[2]]
+    for c, t, tap, half, nt, j, k in [(0, 0, 0, 0, 0, 0, 0), (3, 5, 8, 1, 1, 3, 3), (1, 1, 4, 0, 1, 2, 1),
+                                      (2, 3, 5, 1, 0, 1, 3), (0, 4, 7, 0, 0, 3, 2), (3, 2, 2, 1, 1, 0, 0)]:
+        np.testing.assert_allclose(w43[c, t, tap, half, nt, j, k], G43[t][tap, 8 * c + 4 * half + k, 4 * nt + j],
+                                   rtol=1e-6, atol=1e-9)
+    off += 4 * 6 * 9 * 2 * 2 * 4 * 4
     assert off * 4 == _lib.query_weights_blob()
 
 
