@@ -48,9 +48,24 @@ def parse_cam_file(path: str, interval_scale: float = 1.0):
     return intr, extr, float(fields[0]), float(fields[1]) * interval_scale
 
 
-def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512, 640), base: int = 32):
+def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512, 640), base: int = 32,
+                                cache: "dict | None" = None, cache_size: int = 0):
     """-> (float32 HxWx3 in [0,1], adjusted intrinsics).  `intrinsics` is modified in place too,
-    as the reference does."""
+    as the reference does.
+
+    `cache` (an insertion-ordered dict used as an LRU of at most `cache_size` entries) keeps the decoded,
+    rescaled and cropped pixels per (path, img_res) together with the scale and crop offsets the
+    intrinsics are adjusted by: in an eval run every view is decoded as the reference view of one
+    sample and again as a source view of several neighbours.  The returned pixel array is then
+    shared between samples (read-only use: np.stack copies it into the sample)."""
+    key = (path, tuple(img_res), base)
+    if cache is not None and key in cache:
+        arr, scale, left, top = cache.pop(key)
+        cache[key] = (arr, scale, left, top)            # most recently used last
+        intrinsics[:2, :] *= scale
+        intrinsics[0, -1] -= left
+        intrinsics[1, -1] -= top
+        return arr, intrinsics
     img = Image.open(path)
     w_src, h_src = img.size
     h_t, w_t = img_res
@@ -71,6 +86,10 @@ def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512,
     arr = np.array(img, dtype=np.float32) / 255.0
     if arr.ndim == 2:
         arr = np.dstack((arr, arr, arr))
+    if cache is not None and cache_size > 0:
+        cache[key] = (arr, scale, left, top)
+        while len(cache) > cache_size:
+            cache.pop(next(iter(cache)))
     return arr, intrinsics
 
 
@@ -79,8 +98,11 @@ class EvalDataset:
 
     def __init__(self, datapath, listfile, mode="test", nviews=5, ndepths=192, interval_scale=1.06,
                  pairfile="pair.txt", cam_subfolder="Cameras", img_subfolder="Rectified/{}/rect_{:0>3}_3_r5000.png",
-                 img_res=(512, 640), dataset_name="dtu"):
+                 img_res=(512, 640), dataset_name="dtu", cache_images: int = 0):
         assert mode == "test"
+        # decoded-image LRU (0 = off, the reference's behaviour: every sample decodes its views again)
+        self.cache_images = int(cache_images)
+        self._img_cache = {} if self.cache_images > 0 else None
         self.datapath, self.nviews, self.ndepths = datapath, nviews, ndepths
         self.interval_scale, self.cam_subfolder, self.img_subfolder = interval_scale, cam_subfolder, img_subfolder
         self.img_res, self.dataset_name = img_res, dataset_name
@@ -104,7 +126,8 @@ class EvalDataset:
             img_path = os.path.join(self.datapath, self.img_subfolder.format(scan, img_vid))
             cam_path = os.path.join(self.datapath, self.cam_subfolder, "{:0>8}_cam.txt".format(vid))
             intr, extr, dmin, dint = parse_cam_file(cam_path, self.interval_scale)
-            img, intr = load_image_rescaled_cropped(img_path, intr, img_res=self.img_res)
+            img, intr = load_image_rescaled_cropped(img_path, intr, img_res=self.img_res, cache=self._img_cache,
+                                                    cache_size=self.cache_images)
             imgs.append(img)
             intr[:2, :] /= 4.0  # feature scale (the network downsamples by 4)
             intr_list.append(intr)

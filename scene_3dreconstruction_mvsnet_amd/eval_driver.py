@@ -122,45 +122,65 @@ def _completer(cq: "queue.Queue", pool, futures: list, device, errors: list):
             errors.append(e)
 
 
-def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: int = 16):
-    """Producer thread: dataset items are decoded by `decoders` helper threads running ahead (PIL's
-    PNG/JPEG decoding releases the GIL), handed over in order, and copied to the device on
-    `copy_stream` while the GPU computes the previous sample."""
+def _decoded_samples(dataset, indices, decoders, decoder_pool):
+    """Dataset items in order, decoded ahead of time: by the worker processes of a DecoderPool
+    (yields (sample, release)), else by `decoders` helper threads (PIL's PNG/JPEG decoding releases
+    the GIL; the numpy part does not, which caps this path at ~50 cfg2 maps/s)."""
+    if decoder_pool is not None:
+        for s in decoder_pool.imap(indices):
+            yield s, (lambda s=s: decoder_pool.release(s))
+        return
     from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, decoders)) as pool:
+        ahead = 2 * max(1, decoders)
+        futs = {}
+        nxt = 0
+        for pos in range(len(indices)):
+            while nxt < len(indices) and nxt < pos + ahead:
+                futs[nxt] = pool.submit(dataset.__getitem__, indices[nxt])
+                nxt += 1
+            yield futs.pop(pos).result(), (lambda: None)
+
+
+def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: int = 16, decoder_pool=None,
+            keep_ref_image: bool = True):
+    """Producer thread: decoded samples (see _decoded_samples) are handed over in order and copied to
+    the device on `copy_stream` while the GPU computes the previous sample."""
     try:
-        with ThreadPoolExecutor(max_workers=max(1, decoders)) as pool:
-            ahead = 2 * max(1, decoders)
-            futs = {}
-            nxt = 0
-            for pos, idx in enumerate(indices):
-                while nxt < len(indices) and nxt < pos + ahead:
-                    futs[nxt] = pool.submit(dataset.__getitem__, indices[nxt])
-                    nxt += 1
-                t0 = _now()
-                s = futs.pop(pos).result()
-                _tick("loader.dataset_wait", t0)
-                t0 = _now()
-                src = [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None]
-                       for k in ("imgs", "proj_matrices", "depth_values")]
-                _tick("loader.prep", t0)
-                t0 = _now()
-                with torch.cuda.stream(copy_stream):
-                    # pageable -> device: the HIP runtime stages through its own pinned chunks; measured
-                    # faster here than an explicit host copy into a torch pinned buffer (1.5-2 GB/s)
-                    dev = [t.to(device) for t in src]
-                    ready = torch.cuda.Event()
-                    ready.record(copy_stream)
-                _tick("loader.h2d", t0)
-                t0 = _now()
-                q.put((idx, s, dev, ready))
-                _tick("loader.q_put", t0)
+        it = _decoded_samples(dataset, indices, decoders, decoder_pool)
+        for pos, idx in enumerate(indices):
+            t0 = _now()
+            s, release = next(it)
+            _tick("loader.dataset_wait", t0)
+            t0 = _now()
+            src = [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None]
+                   for k in ("imgs", "proj_matrices", "depth_values")]
+            _tick("loader.prep", t0)
+            t0 = _now()
+            with torch.cuda.stream(copy_stream):
+                # pageable -> device: the HIP runtime stages through its own pinned chunks; measured
+                # faster here than an explicit host copy into a torch pinned buffer (1.5-2 GB/s)
+                dev = [t.to(device) for t in src]
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            _tick("loader.h2d", t0)
+            if decoder_pool is not None:
+                # the pageable copy above has left the shared-memory slot (the runtime staged it);
+                # what the writers need later (the reference image) is copied out before the slot is reused
+                s = dict(s)
+                s["imgs"] = np.array(s["imgs"][:1]) if keep_ref_image else None
+            release()
+            t0 = _now()
+            q.put((idx, s, dev, ready))
+            _tick("loader.q_put", t0)
     except BaseException as e:  # noqa: BLE001 - re-raised by the consumer
         q.put(e)
     q.put(None)
 
 
 def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 1, device=None,
-                       writers: int = 16, save_images: bool = True, decoders: int = 16):
+                       writers: int = 16, save_images: bool = True, decoders: int = 16, decoder_procs: int = 0,
+                       decoder_pool=None):
     """Run `model` over dataset items rank::world and write the reference's per-view files.
 
     dataset[i] -> dict with "imgs" [N,3,H,W], "proj_matrices" [N,4,4], "depth_values" [D],
@@ -170,7 +190,9 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
     a copy stream), the forward passes
     on the current stream, one completion thread (D2H of finished samples on its own stream) and
     `writers` threads that encode the PFM / PNG / cam files.  MVS_DRIVER_TRACE=1 prints where the
-    host time went.
+    host time went.  `decoder_procs` > 0 (or a ready `decoder_pool`) decodes in worker processes with a
+    shared-memory ring instead of threads (decoder_pool.DecoderPool: the counterpart of the reference's
+    DataLoader workers, eval.py:305).
     Returns the list of dataset indices this rank processed.
     """
     device = device or torch.device("cuda", torch.cuda.current_device())
@@ -181,7 +203,12 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
     with torch.cuda.device(device):
         copy_stream = torch.cuda.Stream(device)
         compute = torch.cuda.current_stream(device)
-        th = threading.Thread(target=_loader, args=(dataset, mine, device, copy_stream, q, decoders), daemon=True)
+        own_pool = None
+        if decoder_pool is None and decoder_procs > 0:
+            from .decoder_pool import DecoderPool
+            own_pool = decoder_pool = DecoderPool(dataset, procs=decoder_procs)
+        th = threading.Thread(target=_loader, args=(dataset, mine, device, copy_stream, q, decoders, decoder_pool,
+                                                    save_images), daemon=True)
         th.start()
         futures = []
         cq: "queue.Queue" = queue.Queue(maxsize=4 * max(1, writers))
@@ -212,7 +239,7 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
                     done.record(compute)
                     K = np.asarray(s["intrinsics"][0]) if "intrinsics" in s else None
                     E = np.asarray(s["extrinsics"][0]) if "extrinsics" in s else None
-                    img = np.asarray(s["imgs"][0], np.float32) if save_images else None
+                    img = np.asarray(s["imgs"][0], np.float32) if (save_images and s.get("imgs") is not None) else None
                     _tick("main.d2h_submit", t0)
                     t0 = _now()
                     cq.put((done, out, (outdir, s["filename"], K, E, img)))   # bounded: back-pressure
@@ -226,6 +253,8 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
             for f in futures:
                 f.result()
         th.join()
+        if own_pool is not None:
+            own_pool.close()
     if _TRACE:
         print("[driver trace, seconds] " + ", ".join(f"{k}={v:.3f}" for k, v in sorted(_trace.items())), flush=True)
         _trace.clear()

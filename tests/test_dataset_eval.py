@@ -4,6 +4,7 @@ datasets/dataloader_eval.MVSDataset on the same seeded synthetic dataset
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset, parse_pair_file
@@ -34,3 +35,70 @@ def test_parse_pair_file(tmp_path):
     listfile = write_synthetic_dataset(str(tmp_path))
     pairs = parse_pair_file(os.path.join(os.path.dirname(listfile), "data", "pair.txt"))
     assert pairs[0] == (0, [1, 2, 3]) and pairs[3] == (3, [0, 1, 2])
+
+
+def test_image_cache_gives_identical_samples(tmp_path):
+    """EvalDataset(cache_images=N): decoded views are reused between samples -- same arrays, same
+    adjusted intrinsics as the uncached (reference-like) path."""
+    from synthetic_dataset import write_synthetic_dataset
+    from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset
+    listfile = write_synthetic_dataset(str(tmp_path))
+    kw = dict(mode="test", nviews=3, ndepths=16, interval_scale=1.06, img_res=(96, 128), dataset_name="dtu")
+    import os
+    plain = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, **kw)
+    cached = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, cache_images=3, **kw)
+    for rounds in range(2):
+        for i in range(len(plain)):
+            a, b = plain[i], cached[i]
+            assert a["filename"] == b["filename"]
+            for k in ("imgs", "proj_matrices", "depth_values"):
+                np.testing.assert_array_equal(a[k], b[k])
+            for x, y in zip(a["intrinsics"] + a["extrinsics"], b["intrinsics"] + b["extrinsics"]):
+                np.testing.assert_array_equal(x, y)
+    assert 0 < len(cached._img_cache) <= 3
+
+
+def test_decoder_pool_delivers_the_dataset_in_order(tmp_path):
+    """Worker processes + shared-memory ring: every sample equals dataset[i], in order, also when
+    the consumer never releases explicitly and when there are more samples than slots."""
+    import os
+    from synthetic_dataset import write_synthetic_dataset
+    from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset
+    from scene_3dreconstruction_mvsnet_amd.decoder_pool import DecoderPool
+    listfile = write_synthetic_dataset(str(tmp_path))
+    ds = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, "test", 3, 16, 1.06, img_res=(96, 128),
+                     dataset_name="dtu", cache_images=4)
+    order = list(range(len(ds))) * 3          # 24 samples through 4 slots
+    with DecoderPool(ds, procs=2, chunk=2, slots=4) as pool:
+        seg = pool  # the segment name is only known after the first item
+        for explicit in (True, False):
+            n = 0
+            for i, s in zip(order, pool.imap(order)):
+                want = ds[i]
+                assert s["filename"] == want["filename"]
+                np.testing.assert_array_equal(np.array(s["imgs"]), want["imgs"])
+                np.testing.assert_array_equal(s["proj_matrices"], want["proj_matrices"])
+                np.testing.assert_array_equal(s["depth_values"], want["depth_values"])
+                if explicit:
+                    pool.release(s)
+                n += 1
+            assert n == len(order)
+        name = seg._shm.name
+    assert not os.path.exists(os.path.join("/dev/shm", name.lstrip("/")))   # unlinked on close
+
+
+def test_decoder_pool_forwards_worker_errors(tmp_path):
+    from scene_3dreconstruction_mvsnet_amd.decoder_pool import DecoderPool
+
+    with DecoderPool(_FailingDataset(), procs=1, chunk=1, slots=2, slot_bytes=4096) as pool:
+        it = pool.imap([0, 1, 2])
+        next(it)
+        with pytest.raises(RuntimeError, match="item 1 failed"):
+            next(it)
+
+
+class _FailingDataset:
+    def __getitem__(self, i):
+        if i == 1:
+            raise KeyError("broken sample")
+        return {"imgs": np.zeros((1, 3, 4, 4), np.float32), "filename": str(i)}

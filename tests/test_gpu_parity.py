@@ -573,6 +573,14 @@ def test_dataset_to_pfm_end_to_end(tmp_path):
     dv = ds[1]["depth_values"]
     assert d.min() >= dv[0] - 1e-3 and d.max() <= dv[-1] + 1e-3
     assert (out / "scan9" / "confidence" / "00000001.pfm").exists()
+    # the same run fed by decoder PROCESSES through the shared-memory ring (decoder_pool.py): same files
+    out2 = tmp_path / "out_procs"
+    ds2 = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, "test", 3, 16, 1.06,
+                      img_res=(96, 128), dataset_name="dtu", cache_images=8)
+    assert save_depth_sharded(model, ds2, str(out2), rank=1, world=4, device=DEV, decoder_procs=2) == [1, 5]
+    for rel in ("scan1/depth_est/00000001.pfm", "scan9/confidence/00000001.pfm", "scan1/images/00000001.png",
+                "scan9/cams/00000001_cam.txt"):
+        assert (out / rel).read_bytes() == (out2 / rel).read_bytes(), rel
 
 
 # ------------------------------------------------------------------------------ replicas / threads (b5)

@@ -18,7 +18,7 @@ from scene_3dreconstruction_mvsnet_amd import MVSNet, synthetic  # noqa: E402
 from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset  # noqa: E402
 from scene_3dreconstruction_mvsnet_amd.eval_driver import save_depth_sharded, write_cam  # noqa: E402
 
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 98
 H, W = 512, 640
 root = tempfile.mkdtemp(prefix="mvs_ds_")
 data = os.path.join(root, "data")
@@ -51,10 +51,23 @@ t0 = time.perf_counter()
 ds[0]
 print(f"one dataset item (5 PNG decodes + cams): {(time.perf_counter() - t0) * 1e3:.1f} ms")
 out = os.path.join(root, "out")
-for dec in (1, 8, 16, 32):
+for dec in (1, 16):
     save_depth_sharded(model, ds, out, device=dev, decoders=dec, save_images=False)
     t0 = time.perf_counter()
     save_depth_sharded(model, ds, out, device=dev, decoders=dec, save_images=False)
     dt = time.perf_counter() - t0
-    print(f"decoders={dec}: {len(ds) / dt:.1f} maps/s ({dt / len(ds) * 1e3:.2f} ms per sample, {len(ds)} samples)")
+    print(f"decoder threads={dec}: {len(ds) / dt:.1f} maps/s ({dt / len(ds) * 1e3:.2f} ms per sample, {len(ds)} samples)")
+# worker processes + shared-memory ring (decoder_pool.py), without / with the decoded-image cache;
+# the pool is kept alive across the two runs so that process start-up is not in the second timing
+from scene_3dreconstruction_mvsnet_amd.decoder_pool import DecoderPool  # noqa: E402
+for procs in (8, 16):
+    for cache in (0, 64):
+        dsp = EvalDataset(data, listfile, "test", 5, 192, 1.06, img_res=(H, W), dataset_name="dtu", cache_images=cache)
+        with DecoderPool(dsp, procs=procs, chunk=4) as pool:
+            save_depth_sharded(model, dsp, out, device=dev, save_images=False, decoder_pool=pool)
+            t0 = time.perf_counter()
+            save_depth_sharded(model, dsp, out, device=dev, save_images=False, decoder_pool=pool)
+            dt = time.perf_counter() - t0
+        print(f"decoder processes={procs} image cache={cache}: {len(ds) / dt:.1f} maps/s "
+              f"({dt / len(ds) * 1e3:.2f} ms per sample, {len(ds)} samples)")
 shutil.rmtree(root, ignore_errors=True)
