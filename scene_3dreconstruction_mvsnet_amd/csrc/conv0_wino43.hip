@@ -100,11 +100,25 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
     float* wlds = tile + TILE_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
-    int b = blockIdx.x;
-    const int bx = b % nbx; b /= nbx;
-    const int by = b % nby;
-    const int bz = b / nby;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY, nbz = (D + TZ - 1) / TZ;
+    // Block -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 names the XCD: speed only,
+    // never correctness) and every XCD has its own L2, so halo rows / planes shared by neighbouring
+    // tiles are only re-read from L2 when the neighbours run on the SAME XCD, close in time.  Each XCD
+    // therefore owns a band of nby/8 tile rows and walks it z-fastest: consecutive blocks of an XCD
+    // share two of their six input planes, neighbouring rows follow nbz blocks later.
+    int bx, by, bz;
+    if (nby % 8 == 0 && gridDim.x % 8 == 0) {
+        const int xcd = blockIdx.x & 7, rows = nby >> 3;
+        int i = blockIdx.x >> 3;
+        bz = i % nbz; i /= nbz;
+        by = xcd * rows + i % rows;
+        bx = i / rows;
+    } else {
+        int b = blockIdx.x;
+        bx = b % nbx; b /= nbx;
+        by = b % nby;
+        bz = b / nby;
+    }
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
     const size_t HW8 = (size_t)H * W * 8, V8 = (size_t)D * HW8;
 

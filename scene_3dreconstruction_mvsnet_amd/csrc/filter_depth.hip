@@ -34,10 +34,10 @@ __device__ float remap_linear(const float* __restrict__ src, int h, int w, float
     const float v10 = (y1 && x0) ? src[(size_t)(iy + 1) * w + ix] : 0.f;
     const float v11 = (y1 && x1) ? src[(size_t)(iy + 1) * w + ix + 1] : 0.f;
     // separate mul/add (no contraction): OpenCV's scalar float path is not FMA-fused
-    float r = __fmul_rn(v00, (1.f - fy) * (1.f - fx));
-    r = __fadd_rn(r, __fmul_rn(v01, (1.f - fy) * fx));
-    r = __fadd_rn(r, __fmul_rn(v10, fy * (1.f - fx)));
-    r = __fadd_rn(r, __fmul_rn(v11, fy * fx));
+    float r = __fmul_rn(v00, __fmul_rn(1.f - fy, 1.f - fx));
+    r = __fadd_rn(r, __fmul_rn(v01, __fmul_rn(1.f - fy, fx)));
+    r = __fadd_rn(r, __fmul_rn(v10, __fmul_rn(fy, 1.f - fx)));
+    r = __fadd_rn(r, __fmul_rn(v11, __fmul_rn(fy, fx)));
     return r;
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void filter_depth_kernel(FilterParams P) {
                      k2 = dot3(Kr + 6, w0, w1, w2);
         const float xr = (float)(k0 / k2), yr = (float)(k1 / k2);                   // eval.py:554-556
         const double dx = (double)xr - (double)x, dy = (double)yr - (double)y;
-        const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));  // eval.py:574
+        const double dist = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));  // eval.py:574
         const float rel = fabsf(d_rep - d_ref) / d_ref;                             // eval.py:577-578
         const bool ok = (dist < P.condmask_pixel) && (rel < P.condmask_depth);      // eval.py:582
         geo += ok ? 1 : 0;
@@ -128,18 +128,21 @@ __global__ __launch_bounds__(256) void filter_depth_kernel(FilterParams P) {
     const float* Ri = RM + 18;
     const float* t = RM + 27;
     const double gx = (double)x + 0.5, gy = (double)y + 0.5;
-    const double c0 = dot3(Kri, gx, gy, 1.0) * avg - (double)t[0];
-    const double c1 = dot3(Kri + 3, gx, gy, 1.0) * avg - (double)t[1];
-    const double c2 = dot3(Kri + 6, gx, gy, 1.0) * avg - (double)t[2];
+    const double c0 = __dsub_rn(__dmul_rn(dot3(Kri, gx, gy, 1.0), avg), (double)t[0]);
+    const double c1 = __dsub_rn(__dmul_rn(dot3(Kri + 3, gx, gy, 1.0), avg), (double)t[1]);
+    const double c2 = __dsub_rn(__dmul_rn(dot3(Kri + 6, gx, gy, 1.0), avg), (double)t[2]);
     double* W = P.xyz_world + o * 3;
-    W[0] = dot3(Ri, c0, c1, c2) * 1.0531;
-    W[1] = dot3(Ri + 3, c0, c1, c2) * 1.0531;
+    W[0] = __dmul_rn(dot3(Ri, c0, c1, c2), 1.0531);
+    W[1] = __dmul_rn(dot3(Ri + 3, c0, c1, c2), 1.0531);
     W[2] = dot3(Ri + 6, c0, c1, c2);
 }
 
 // ---- host: float32 inverse by LU with partial pivoting (what numpy.linalg.inv's sgesv does) ----
+// every multiply / add rounded separately (no contraction into fma): oracle/filter_oracle.py fixes
+// exactly this order, and the kernel's integer outputs are held to bit-equality with it
 template <int N>
 static bool inv_f32(const float* a, float* out) {
+#pragma clang fp contract(off)
     float lu[N][N];
     int piv[N];
     for (int i = 0; i < N; ++i)
@@ -173,6 +176,7 @@ static bool inv_f32(const float* a, float* out) {
 }
 
 static void matmul4_rows3(const float* a, const float* b, float* out12) {
+#pragma clang fp contract(off)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 4; ++j) {
             float s = 0.f;

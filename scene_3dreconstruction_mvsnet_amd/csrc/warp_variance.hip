@@ -294,12 +294,12 @@ static bool force_depth_fastest() {
 int launch_warp_variance16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                            int h, int w, int dtype, hipStream_t s) {
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
-    // The tap-cache kernel is opt-in here (MVS_WARP_TC16=1): with 16-bit features a tap is one 16-byte
-    // load already, and the plain kernel below is the faster one at cfg5 (0.21 vs 0.25 ms) and cfg3
-    // (1.9 vs 3.2 ms: larger images move further per depth step and lose the depth-fastest L2 order).
+    // The tap-cache kernel (second form, warp_variance_tc.hip) is the default here too: cfg5 0.20 ->
+    // 0.15 ms, cfg3 1.84 -> 1.39 ms against the plain kernel below (MVS_WARP_TC16=0 selects it; the
+    // FIRST form of the tap-cache kernel had been slower than the plain kernel with 16-bit features).
     static const bool use_tc = [] {
         const char* e = getenv("MVS_WARP_TC16");
-        return e && e[0] == '1';
+        return !(e && e[0] == '0');
     }();
     if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 8 < ((size_t)1 << 31))
         return launch_warp_variance_tc16(feats16, rt, dv, var, N, D, h, w, dtype, s);

@@ -322,7 +322,12 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
                                                                 const float* __restrict__ rt,
                                                                 const float* __restrict__ dv,
                                                                 void* __restrict__ var, int N, int D, int h,
-                                                                int w, int slab) {
+                                                                int w, int slab, int depth_fastest) {
+    // block order: pixel block fastest (default: the features stay L2-resident anyway), or depth slab
+    // fastest when the feature maps exceed the L2s (1600x1184 inputs): blocks resident together then
+    // work on the same pixels at neighbouring depths and share their source footprints in L2
+    const int pblk = depth_fastest ? blockIdx.y : blockIdx.x;
+    const int dblk = depth_fastest ? blockIdx.x : blockIdx.y;
     constexpr unsigned FES = FDT == MVS_F32 ? 4u : 2u;   // bytes per feature element
     constexpr unsigned VES = DT == MVS_F32 ? 4u : 2u;    // bytes per volume element
     constexpr int LPP = 32 / CPT;                        // lanes per pixel: 4 (CPT = 8) or 8 (CPT = 4)
@@ -330,11 +335,11 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
     const int sub = threadIdx.x & (LPP - 1);             // this thread's channels: sub * CPT .. + CPT - 1
     const int pl = (sub * CPT) >> 3, cin = (sub * CPT) & 7;   // C8 plane and first channel inside it
     const int hw = h * w;
-    const int p_raw = blockIdx.x * (256 / LPP) + (threadIdx.x / LPP);
+    const int p_raw = pblk * (256 / LPP) + (threadIdx.x / LPP);
     const bool live = p_raw < hw;
     const int p = live ? p_raw : hw - 1;  // keep whole quads / waves converged for the DPP exchange
     const int y = p / w, x = p - y * w;
-    const int d0 = blockIdx.y * slab, d1 = min(d0 + slab, D);
+    const int d0 = dblk * slab, d1 = min(d0 + slab, D);
     const float sx = (float)w / (float)(w - 1), sy = (float)h / (float)(h - 1);
     const float fx = (float)x, fy = (float)y;
     const float inv_n = 1.0f / (float)N;
@@ -454,10 +459,18 @@ template <int DT, int FDT, int CPT>
 int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* var, int N, int D, int h, int w,
                   int slab, bool nts, hipStream_t s) {
     constexpr int pix = 256 / (32 / CPT);
-    const dim3 grid((h * w + pix - 1) / pix, (D + slab - 1) / slab);
+    constexpr size_t fes = FDT == MVS_F32 ? 4 : 2;
+    // all views' features against the 32 MB of aggregate L2 (MVS_WARP_DEPTH_FASTEST=1 forces the order)
+    static const bool force_df = [] {
+        const char* e = getenv("MVS_WARP_DEPTH_FASTEST");
+        return e && e[0] == '1';
+    }();
+    const int df = (force_df || (size_t)N * h * w * 32 * fes > ((size_t)24 << 20)) ? 1 : 0;
+    const unsigned npb = (h * w + pix - 1) / pix, nsl = (D + slab - 1) / slab;
+    const dim3 grid = df ? dim3(nsl, npb) : dim3(npb, nsl);
 #define MVS_TC2(NV)                                                                                               \
-    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab); \
-    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab);
+    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df); \
+    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df);
     switch (N - 1) {
         case 1: MVS_TC2(1) break;
         case 2: MVS_TC2(2) break;

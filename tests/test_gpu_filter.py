@@ -1,7 +1,6 @@
 """GPU parity of the depth-map filter / fusion kernel (mvs_filter_depth through the C ABI) against
-oracle/filter_oracle.py.  Integer outputs (geo_sum, masks) must be equal except at
-pixels that sit on a threshold or on a 1/32-pixel quantisation boundary of the sampler, where the
-last bit of a float64 product decides; those are bounded to 0.2 % of the pixels."""
+oracle/filter_oracle.py: every output bit-equal.  (The oracle itself is "parity
+unpinned" against the reference -- cv2 cannot be imported here -- see its header.)"""
 import os
 
 import numpy as np
@@ -18,26 +17,20 @@ pytestmark = pytest.mark.gpu
 
 
 def _compare(out, want, pairs):
+    """Bit-equality: oracle/filter_oracle.py fixes one operation order (unfused, left to right) and
+    the kernel + mvs_filter_compose follow it, so nothing is left to tolerances."""
     geo = out["geo_sum"].cpu().numpy()
     avg = out["depth_avg"].cpu().numpy()
     masks = out["masks"].cpu().numpy()
     xyz = out["xyz_world"].cpu().numpy()
-    bad = 0
-    total = 0
     for i in range(len(pairs)):
         w = want[i]
-        same = geo[i] == w["geo_sum"]
-        bad += int((~same).sum())
-        total += same.size
-        assert np.abs(geo[i] - w["geo_sum"]).max() <= 1
-        np.testing.assert_allclose(avg[i][same], w["depth_avg"][same], rtol=1e-4)
-        tight = np.isclose(avg[i], w["depth_avg"], rtol=2e-6, atol=0) & same   # float32 camera-product noise
-        assert tight.mean() > 0.995, tight.mean()
+        np.testing.assert_array_equal(geo[i], w["geo_sum"])
         np.testing.assert_array_equal(masks[i, 0], w["photo"])
-        np.testing.assert_array_equal(masks[i, 1][same], w["geo"][same])
-        np.testing.assert_array_equal(masks[i, 2][same], w["final"][same])
-        np.testing.assert_allclose(xyz[i][tight.reshape(-1)], w["xyz_world"][tight.reshape(-1)], rtol=1e-5, atol=2e-3)   # atol = 3e-6 of the scene depth (cancellation near x,y = 0)
-    assert bad <= 0.002 * total, (bad, total)
+        np.testing.assert_array_equal(masks[i, 1], w["geo"])
+        np.testing.assert_array_equal(masks[i, 2], w["final"])
+        np.testing.assert_array_equal(avg[i], w["depth_avg"])          # NaN == NaN positions included
+        np.testing.assert_array_equal(xyz[i], w["xyz_world"])
 
 
 @pytest.mark.parametrize("V,h,w,nvf", [(6, 64, 80, 10), (5, 40, 56, 2), (12, 128, 160, 10)])
@@ -84,11 +77,11 @@ def test_filter_depth_from_files(tmp_path):
     # the cam files round-trip through str(float32): same values as the arrays
     want = fo.filter_views(depths, confs, Ks, Es, pairs, geomask=2)
     n_want = sum(int(w["final"].sum()) for w in want)
-    assert abs(len(verts) - n_want) <= 0.01 * n_want + 2 and len(verts) == len(cols) > 0
+    assert len(verts) == n_want and len(verts) == len(cols) > 0
     m0 = np.array(Image.open(os.path.join(root, "mask", "00000000_final.png"))) > 0
-    assert (m0 != want[0]["final"]).mean() < 0.005
+    np.testing.assert_array_equal(m0, want[0]["final"])
     first = want[0]["xyz_world"][m0.reshape(-1)]
-    np.testing.assert_allclose(verts[:len(first)], first, rtol=1e-4)
+    np.testing.assert_allclose(verts[:len(first)], first, rtol=1e-6)   # PLY vertices are float32
     np.testing.assert_array_equal(cols[:len(first)], imgs[0][1::4, 1::4][m0])
     raw = open(ply, "rb").read()
     assert raw.split(b"end_header\n")[1].__len__() == 15 * len(verts)

@@ -332,6 +332,8 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     # depth-slab-fastest block order of the warp kernels (default only when the features exceed L2)
     ({"MVS_WARP_DEPTH_FASTEST": "1"}, ("24", "24", "40", "f32", "bf16")),
     ({"MVS_WARP_DEPTH_FASTEST": "1", "MVS_WARP_TC": "0"}, ("16", "16", "32", "f32")),
+    ({"MVS_WARP_DEPTH_FASTEST": "1", "MVS_WARP_TC16": "0"}, ("16", "16", "32", "f16", "bf16")),   # plain 16-bit kernel
+    ({"MVS_WARP_TC16": "0"}, ("16", "16", "32", "bf16")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a
