@@ -16,6 +16,11 @@
 
 namespace mvs {
 
+// No fused multiply-adds anywhere in this file: HIP's __dmul_rn / __dadd_rn / __fmul_rn are plain `*`
+// and `+` that hipcc contracts into fma under its default -ffp-contract=fast, while the oracle (numpy
+// elementwise arithmetic) rounds every product and sum separately; the outputs are held to bit-equality.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ int cv_round(float v) {
     const float r = rintf(v);
     return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : INT_MIN;  // NaN -> INT_MIN

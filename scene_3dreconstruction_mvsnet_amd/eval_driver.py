@@ -30,21 +30,16 @@ from . import data_io, sharding
 
 
 def write_cam(file: str, K, R, depth_params) -> None:
-    """Same text as the reference's write_cam (eval.py:107-126)."""
+    """cams/{view}_cam.txt in the layout the filter stage parses back (reference eval.py:107-126):
+    an `extrinsic` block of four rows, an `intrinsic` block of three rows -- every number followed by
+    one blank, as `str()` prints it -- and a last line with the four depth parameters."""
+    def block(title, mat, n):
+        rows = ["".join(str(mat[i][j]) + " " for j in range(n)) for i in range(n)]
+        return title + "\n" + "\n".join(rows) + "\n\n"
+
+    text = block("extrinsic", R, 4) + block("intrinsic", K, 3) + " ".join(str(p) for p in depth_params[:4]) + "\n"
     with open(file, "w") as f:
-        f.write("extrinsic\n")
-        for i in range(4):
-            for j in range(4):
-                f.write(str(R[i][j]) + " ")
-            f.write("\n")
-        f.write("\n")
-        f.write("intrinsic\n")
-        for i in range(3):
-            for j in range(3):
-                f.write(str(K[i][j]) + " ")
-            f.write("\n")
-        f.write("\n" + str(depth_params[0]) + " " + str(depth_params[1]) + " " + str(depth_params[2]) +
-                " " + str(depth_params[3]) + "\n")
+        f.write(text)
 
 
 def _write_sample(job) -> None:
