@@ -14,12 +14,13 @@
 
 #include "mvs_internal.h"
 
-namespace mvs {
-
-// No fused multiply-adds anywhere in this file: HIP's __dmul_rn / __dadd_rn / __fmul_rn are plain `*`
-// and `+` that hipcc contracts into fma under its default -ffp-contract=fast, while the oracle (numpy
-// elementwise arithmetic) rounds every product and sum separately; the outputs are held to bit-equality.
+// No fused multiply-adds anywhere in this file (the Makefile also builds it with -ffp-contract=off):
+// HIP's __dmul_rn / __dadd_rn / __fmul_rn are plain `*` and `+` that hipcc contracts into fma under its
+// default -ffp-contract=fast, while the oracle (numpy elementwise arithmetic) rounds every product and
+// sum separately; the outputs are held to bit-equality.
 #pragma clang fp contract(off)
+
+namespace mvs {
 
 __device__ __forceinline__ int cv_round(float v) {
     const float r = rintf(v);
