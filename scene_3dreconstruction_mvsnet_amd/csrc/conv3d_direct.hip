@@ -285,6 +285,10 @@ constexpr int NPIECE = HZ * HY * HX * 2;
 constexpr int PPT = (NPIECE + 255) / 256;  // 16
 }  // namespace pl
 
+// Persistent blocks (two per CU) loop over the tiles; the halo tile of the NEXT tile is requested into
+// registers before the current tile is multiplied from LDS, so the staging latency -- which bounded the
+// one-tile-per-block form at 2.2 TB/s (load everything, wait, write LDS, compute) -- is hidden behind
+// the 864 FMAs per thread of the current tile.
 template <int DT>
 __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict__ x,  // storage DT
                                                           const float* __restrict__ wgt,  // [27][8]
@@ -294,82 +298,126 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
     __shared__ __attribute__((aligned(16))) float tile[HZ * HY * HX * 8];
     const int tid = threadIdx.x;
     const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
-    int b = blockIdx.x;
-    const int bx = b % nbx; b /= nbx;
-    const int by = b % nby;
-    const int bz = b / nby;
-    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    const int ntiles = nbx * nby * ((D + TZ - 1) / TZ);
+    int x0 = 0, y0 = 0, z0 = 0;
 
+    // Staging bookkeeping, ONCE per thread: piece i of this thread is halo voxel (hz, hy, hx), 16-byte
+    // half `half`, the same for every tile.  Decomposing p = tid + 256 i by the non-power-of-two tile
+    // extents, bounds checks and 64-bit addresses for 16 pieces cost ~400 VALU instructions -- per TILE
+    // that was a third of the kernel's vector time (SQ_ACTIVE_INST_VALU = 80 % of its wall time).  Per
+    // tile only a scalar base offset and six scalar range limits are left.
+    int rel[PPT], lo[PPT];          // element offset relative to the tile's halo origin; LDS float offset
+    unsigned pos[PPT];              // hz | hy << 8 | hx << 16 (0xFFFFFF.. = no such piece)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * 256;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, tt = v / HX;
+        const int hy = tt % HY, hz = tt / HY;
+        const bool have = p < NPIECE;
+        rel[i] = have ? ((hz * H + hy) * W + hx) * 8 + half * 4 : 0;
+        pos[i] = have ? (unsigned)(hz | (hy << 8) | (hx << 16)) : 0x00FFFFFFu;
+        lo[i] = have ? v * 8 + ((half ^ ((hx >> 3) & 1)) * 4) : -1;
+    }
     float4 stg[PPT];
+    auto load_tile = [&](int t) {   // global -> registers (zeros outside the volume)
+        const int bx = t % nbx, by = (t / nbx) % nby, bz = t / (nbx * nby);
+        x0 = bx * TX; y0 = by * TY; z0 = bz * TZ;
+        // halo origin (z0-1, y0-1, x0-1) as a (possibly negative) element offset: wave-uniform
+        const long long base = ((((long long)(z0 - 1) * H + (y0 - 1)) * W) + (x0 - 1)) * 8;
+        // valid halo index ranges of this tile (scalar): hz in [zl, zh] etc.
+        const int zl = max(0, 1 - z0), zh = min(HZ - 1, D - z0), yl = max(0, 1 - y0), yh = min(HY - 1, H - y0),
+                  xl = max(0, 1 - x0), xh = min(HX - 1, W - x0);
+        const bool interior = zl == 0 && zh == HZ - 1 && yl == 0 && yh == HY - 1 && xl == 0 && xh == HX - 1;
+        if (interior) {            // wave-uniform: no masks at all
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int p = tid + i * 256;
-        const int half = p & 1, v = p >> 1;
-        const int hx = v % HX, t = v / HX;
-        const int hy = t % HY, hz = t / HY;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = p < NPIECE && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t off = ok ? (((size_t)gz * H + gy) * W + gx) * 8 + half * 4 : 0;
+            for (int i = 0; i < PPT; ++i) {
 #if MVS_ABLATE == 6  // diagnostic: no staging loads
-        (void)off;
-        stg[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+                stg[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 #else
-        const f32x4 val = St<DT>::load4(x, off);
-        stg[i] = ok ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4 val = St<DT>::load4(x, (size_t)(base + (pos[i] != 0x00FFFFFFu ? rel[i] : (int)(-base))));
+                stg[i] = make_float4(val[0], val[1], val[2], val[3]);
 #endif
-    }
+            }
+        } else {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int p = tid + i * 256;
-        const int half = p & 1, v = p >> 1;
-        const int hx = v % HX;
-        if (p < NPIECE) *reinterpret_cast<float4*>(tile + v * 8 + ((half ^ ((hx >> 3) & 1)) * 4)) = stg[i];
-    }
-    __syncthreads();
+            for (int i = 0; i < PPT; ++i) {
+                const int hz = pos[i] & 255, hy = (pos[i] >> 8) & 255, hx = pos[i] >> 16;
+                const bool ok = hz >= zl && hz <= zh && hy >= yl && hy <= yh && hx >= xl && hx <= xh;
+#if MVS_ABLATE == 6
+                stg[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#else
+                const f32x4 val = St<DT>::load4(x, ok ? (size_t)(base + rel[i]) : (size_t)0);
+                stg[i] = ok ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+            }
+        }
+    };
+    auto store_tile = [&]() {       // registers -> LDS
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (lo[i] >= 0) *reinterpret_cast<float4*>(tile + lo[i]) = stg[i];
+    };
 
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    load_tile(t);
+    store_tile();
+    __syncthreads();
     const int tx = tid & 31, ty = tid >> 5;  // thread -> (y, x) of the tile, 4 z outputs
-    float acc[TZ];
     const float bv = bias[0];
-#pragma unroll
-    for (int j = 0; j < TZ; ++j) acc[j] = bv;
 #if MVS_ABLATE == 5  // diagnostic: one tap only
 #define MVS_PROB_KH 1
 #else
 #define MVS_PROB_KH 3
 #endif
+    for (;;) {
+        const int cx0 = x0, cy0 = y0, cz0 = z0;      // origin of the tile now in LDS
+        const int tn = t + gridDim.x;
+        const bool has_next = tn < ntiles;
+        if (has_next) load_tile(tn);                  // in flight during the FMAs below
+        float acc[TZ];
+#pragma unroll
+        for (int j = 0; j < TZ; ++j) acc[j] = bv;
 #pragma unroll 1
-    for (int kh = 0; kh < MVS_PROB_KH; ++kh)
+        for (int kh = 0; kh < MVS_PROB_KH; ++kh)
 #pragma unroll 1
-        for (int kw = 0; kw < MVS_PROB_KH; ++kw) {
-            const int hx = tx + kw;
-            const int sw = ((hx >> 3) & 1) * 4;
-            const float* vp = tile + ((ty + kh) * HX + hx) * 8;
-            float4 a[HZ], bq[HZ];
+            for (int kw = 0; kw < MVS_PROB_KH; ++kw) {
+                const int hx = tx + kw;
+                const int sw = ((hx >> 3) & 1) * 4;
+                const float* vp = tile + ((ty + kh) * HX + hx) * 8;
+                float4 a[HZ], bq[HZ];
 #pragma unroll
-            for (int c = 0; c < HZ; ++c) {
-                a[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + sw);         // channels 0..3
-                bq[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + (4 - sw));  // channels 4..7
-            }
+                for (int c = 0; c < HZ; ++c) {
+                    a[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + sw);         // channels 0..3
+                    bq[c] = *reinterpret_cast<const float4*>(vp + c * HY * HX * 8 + (4 - sw));  // channels 4..7
+                }
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                // uniform address -> scalar (SMEM) loads, the weights are SGPR operands of the FMAs;
-                // measured 5 % faster than broadcast reads of an LDS copy (one LDS read less per 4 FMAs)
-                const float* wv = wgt + ((kd * 3 + kh) * 3 + kw) * 8;
-                const float4 w0 = make_float4(wv[0], wv[1], wv[2], wv[3]);
-                const float4 w1 = make_float4(wv[4], wv[5], wv[6], wv[7]);
+                for (int kd = 0; kd < 3; ++kd) {
+                    // uniform address -> scalar (SMEM) loads, the weights are SGPR operands of the FMAs;
+                    // measured 5 % faster than broadcast reads of an LDS copy (one LDS read less per 4 FMAs)
+                    const float* wv = wgt + ((kd * 3 + kh) * 3 + kw) * 8;
+                    const float4 w0 = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                    const float4 w1 = make_float4(wv[4], wv[5], wv[6], wv[7]);
 #pragma unroll
-                for (int j = 0; j < TZ; ++j) {
-                    const int c = j + kd;  // input plane of output j through tap kd
-                    acc[j] = fmaf(a[c].x, w0.x, fmaf(a[c].y, w0.y, fmaf(a[c].z, w0.z, fmaf(a[c].w, w0.w, acc[j]))));
-                    acc[j] = fmaf(bq[c].x, w1.x, fmaf(bq[c].y, w1.y, fmaf(bq[c].z, w1.z, fmaf(bq[c].w, w1.w, acc[j]))));
+                    for (int j = 0; j < TZ; ++j) {
+                        const int c = j + kd;  // input plane of output j through tap kd
+                        acc[j] = fmaf(a[c].x, w0.x, fmaf(a[c].y, w0.y, fmaf(a[c].z, w0.z, fmaf(a[c].w, w0.w, acc[j]))));
+                        acc[j] = fmaf(bq[c].x, w1.x, fmaf(bq[c].y, w1.y, fmaf(bq[c].z, w1.z, fmaf(bq[c].w, w1.w, acc[j]))));
+                    }
                 }
             }
-        }
-    const int gy = y0 + ty, gx = x0 + tx;
-    if (gy < H && gx < W) {
+        const int gy = cy0 + ty, gx = cx0 + tx;
+        if (gy < H && gx < W) {
 #pragma unroll
-        for (int j = 0; j < TZ; ++j)
-            if (z0 + j < D) y[((size_t)(z0 + j) * H + gy) * W + gx] = acc[j];
+            for (int j = 0; j < TZ; ++j)
+                if (cz0 + j < D) y[((size_t)(cz0 + j) * H + gy) * W + gx] = acc[j];
+        }
+        if (!has_next) break;
+        __syncthreads();   // every thread is done reading the current tile
+        store_tile();      // the next tile (requested before the FMAs)
+        __syncthreads();
+        t = tn;
     }
 }
 
@@ -381,7 +429,17 @@ static int run_prob(const void* x, void* y, const float* wgt, const float* bias,
     }();
     if (!use_gather || dtype != MVS_F32) {
         using namespace pl;
-        const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+        const int ntiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+        // persistent grid: two blocks per CU (65 KB of LDS each); MVS_PROB_PERSIST=0 = one tile per block
+        static const bool persist = [] {
+            const char* e = getenv("MVS_PROB_PERSIST");
+            return !(e && e[0] == '0');
+        }();
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        const int nb = persist ? (ntiles < 2 * cus ? ntiles : 2 * cus) : ntiles;
         float* yo = static_cast<float*>(y);
         if (dtype == MVS_F32) prob_lds_kernel<MVS_F32><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
         else if (dtype == MVS_F16) prob_lds_kernel<MVS_F16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
