@@ -116,6 +116,49 @@ class EvalDataset:
     def __len__(self):
         return len(self.metas)
 
+    # ---- the sample in three steps (used whole by __getitem__, piecewise by decoder_pool.ViewDecoderPool,
+    # which decodes every view ONCE and shares it between the samples that use it) ----------------
+    def view_plan(self, idx):
+        """-> (filename template, [(image path, cam path), ...]) of sample idx: reference view first."""
+        scan, ref_view, src_views = self.metas[idx]
+        view_ids = [ref_view] + src_views[:self.nviews - 1]
+        views = []
+        for vid in view_ids:
+            img_vid = vid + 1 if self.dataset_name in ("dtu",) else vid
+            views.append((os.path.join(self.datapath, self.img_subfolder.format(scan, img_vid)),
+                          os.path.join(self.datapath, self.cam_subfolder, "{:0>8}_cam.txt".format(vid))))
+        return scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}", views
+
+    def decode_view(self, img_path):
+        """The expensive part: decode + rescale + crop one image.  -> (float32 [3,H,W] contiguous in [0,1],
+        (scale, left, top)): what the intrinsics of any sample using this view are adjusted by."""
+        probe = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
+        arr, probe = load_image_rescaled_cropped(img_path, probe, img_res=self.img_res, cache=self._img_cache,
+                                                 cache_size=self.cache_images)
+        return np.ascontiguousarray(arr.transpose(2, 0, 1)), (float(probe[0, 0]), float(-probe[0, 2]), float(-probe[1, 2]))
+
+    def assemble(self, idx, adjust):
+        """Everything of sample idx except the pixels; adjust[i] = (scale, left, top) of view i."""
+        filename, views = self.view_plan(idx)
+        projs, intr_list, extr_list = [], [], []
+        depth_values = None
+        for i, (_, cam_path) in enumerate(views):
+            intr, extr, dmin, dint = parse_cam_file(cam_path, self.interval_scale)
+            scale, left, top = adjust[i]
+            intr[:2, :] *= scale            # the same in-place float32 updates as load_image_rescaled_cropped
+            intr[0, -1] -= left
+            intr[1, -1] -= top
+            intr[:2, :] /= 4.0
+            intr_list.append(intr)
+            extr_list.append(extr)
+            proj = extr.copy()
+            proj[:3, :4] = np.matmul(intr, proj[:3, :4])
+            projs.append(proj)
+            if i == 0:
+                depth_values = np.arange(dmin, dint * (self.ndepths - 0.5) + dmin, dint, dtype=np.float32)
+        return {"proj_matrices": np.stack(projs), "intrinsics": intr_list, "extrinsics": extr_list,
+                "depth_values": depth_values, "filename": filename}
+
     def __getitem__(self, idx):
         scan, ref_view, src_views = self.metas[idx]
         view_ids = [ref_view] + src_views[:self.nviews - 1]

@@ -171,3 +171,167 @@ class DecoderPool:
 def default_procs() -> int:
     """Decoder processes for one GPU's share of the host (a 1-GPU box of this pool gets 16 cores)."""
     return max(1, min(16, (os.cpu_count() or 2) - 2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# View-level pool: every image is decoded ONCE per run and shared between the samples that use it.
+# ---------------------------------------------------------------------------------------------------
+def _view_worker(dataset, shm_name, slot_bytes, tasks, results):
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        while True:
+            job = tasks.get()
+            if job is _SENTINEL:
+                return
+            path, slot = job
+            try:
+                arr, adjust = dataset.decode_view(path)
+                if arr.nbytes > slot_bytes:
+                    raise ValueError(f"{path}: {arr.nbytes} bytes exceed the slot size {slot_bytes}")
+                np.ndarray(arr.shape, arr.dtype, buffer=shm.buf, offset=slot * slot_bytes)[...] = arr
+                results.put((path, slot, arr.shape, arr.dtype.str, adjust, None))
+            except BaseException:  # noqa: BLE001 - forwarded to the parent
+                results.put((path, slot, None, None, None, traceback.format_exc()))
+    finally:
+        shm.close()
+
+
+class ViewDecoderPool:
+    """Samples in dataset order with `imgs` = LIST of per-view arrays [3,H,W] living in shared memory.
+
+    In an eval run every view is the reference view of one sample and a source view of several
+    neighbours (nviews - 1 on average), so decoding per SAMPLE repeats each PNG decode nviews times
+    (DecoderPool above; a per-worker cache only recovers part of it).  Here the unit of work is the
+    VIEW: the parent walks the samples `lookahead` ahead, asks the workers for every image that is not
+    already in the shared-memory cache (`slots` entries, least recently used first out, entries of
+    samples still ahead or handed out are pinned) and assembles a sample from the cached views and the
+    (cheap, in-parent) camera parsing.  Needs a dataset with `view_plan`, `decode_view`, `assemble`
+    (dataset_eval.EvalDataset); results are bit-identical to `dataset[i]`.
+    """
+
+    def __init__(self, dataset, procs: int = 8, slots: int = 96, lookahead: int = 8, slot_bytes: int | None = None):
+        self.dataset, self.procs, self.slots, self.lookahead = dataset, max(1, procs), slots, max(1, lookahead)
+        self._slot_bytes = slot_bytes
+        self._ctx = mp.get_context("spawn")
+        self._shm = None
+        self._workers, self._tasks, self._results = [], None, None
+
+    def _start(self, first_index):
+        if self._shm is not None:
+            return
+        if self._slot_bytes is None:
+            arr, _ = self.dataset.decode_view(self.dataset.view_plan(first_index)[1][0][0])
+            self._slot_bytes = (arr.nbytes + 4095) // 4096 * 4096
+        self._shm = shared_memory.SharedMemory(create=True, size=self.slots * self._slot_bytes)
+        self._tasks, self._results = self._ctx.Queue(), self._ctx.Queue()
+        for _ in range(self.procs):
+            p = self._ctx.Process(target=_view_worker, args=(self.dataset, self._shm.name, self._slot_bytes,
+                                                             self._tasks, self._results), daemon=True)
+            p.start()
+            self._workers.append(p)
+        self._cache = {}        # path -> [slot, state ('flying' | 'ready'), shape, dtype, adjust, pins]
+        self._free = list(range(self.slots))
+        self._pins_of = {}      # id(sample) -> [paths]
+
+    def close(self):
+        for _ in self._workers:
+            try:
+                self._tasks.put(_SENTINEL)
+            except (OSError, ValueError):
+                pass
+        for p in self._workers:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        self._workers = []
+        if self._shm is not None:
+            self._shm.close()
+            try:
+                self._shm.unlink()
+            except FileNotFoundError:
+                pass
+            self._shm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def release(self, sample):
+        for path in self._pins_of.pop(id(sample), ()):
+            self._cache[path][5] -= 1
+
+    def _request(self, path) -> bool:
+        """Pin `path` for a sample ahead; start its decode if it is not cached.  False = no slot free."""
+        ent = self._cache.get(path)
+        if ent is not None:
+            ent[5] += 1
+            self._cache[path] = self._cache.pop(path)      # most recently used last
+            return True
+        if not self._free:
+            victim = next((k for k, e in self._cache.items() if e[5] == 0 and e[1] == "ready"), None)
+            if victim is None:
+                return False
+            self._free.append(self._cache.pop(victim)[0])
+        slot = self._free.pop()
+        self._cache[path] = [slot, "flying", None, None, None, 1]
+        self._tasks.put((path, slot))
+        return True
+
+    def imap(self, indices):
+        indices = list(indices)
+        if not indices:
+            return
+        self._start(indices[0])
+        plans = {}
+        planned = 0            # samples [0, planned) have their views pinned / requested
+        handed = []
+        for pos in range(len(indices)):
+            while planned < len(indices) and planned < pos + self.lookahead:
+                plan = plans.get(planned) or self.dataset.view_plan(indices[planned])
+                plans[planned] = plan
+                paths = [p for p, _ in plan[1]]
+                got = []
+                for p in paths:
+                    if not self._request(p):
+                        break
+                    got.append(p)
+                if len(got) < len(paths):          # cache full of pinned views: undo and retry later
+                    for p in got:
+                        self._cache[p][5] -= 1
+                    if planned == pos:
+                        if handed:                 # recycle the oldest hand-out the consumer kept
+                            self.release(handed.pop(0))
+                            continue
+                        raise RuntimeError("ViewDecoderPool: `slots` is smaller than one sample's views")
+                    break
+                planned += 1
+            filename, views = plans.pop(pos)
+            paths = [p for p, _ in views]
+            while any(self._cache[p][1] != "ready" for p in paths):
+                try:
+                    path, slot, shape, dtype, adjust, err = self._results.get(timeout=1.0)
+                except queue.Empty:
+                    dead = [p.exitcode for p in self._workers if not p.is_alive()]
+                    if dead:
+                        raise RuntimeError(f"decoder worker died (exit codes {dead})") from None
+                    continue
+                if err is not None:
+                    raise RuntimeError(f"decoding {path} failed in a decoder process:\n{err}")
+                ent = self._cache[path]
+                ent[1:5] = ["ready", shape, dtype, adjust]
+            ents = [self._cache[p] for p in paths]
+            sample = self.dataset.assemble(indices[pos], [e[4] for e in ents])
+            sample["imgs"] = [np.ndarray(e[2], np.dtype(e[3]), buffer=self._shm.buf, offset=e[0] * self._slot_bytes)
+                              for e in ents]
+            self._pins_of[id(sample)] = paths
+            handed.append(sample)
+            handed = [s for s in handed if id(s) in self._pins_of]
+            yield sample

@@ -148,22 +148,30 @@ def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: i
             s, release = next(it)
             _tick("loader.dataset_wait", t0)
             t0 = _now()
-            src = [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None]
-                   for k in ("imgs", "proj_matrices", "depth_values")]
+            per_view = isinstance(s["imgs"], (list, tuple))     # ViewDecoderPool: one shared-memory array per view
+            src = [None if per_view else torch.as_tensor(np.asarray(s["imgs"]), dtype=torch.float32)[None]] + \
+                  [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None] for k in ("proj_matrices", "depth_values")]
             _tick("loader.prep", t0)
             t0 = _now()
             with torch.cuda.stream(copy_stream):
                 # pageable -> device: the HIP runtime stages through its own pinned chunks; measured
                 # faster here than an explicit host copy into a torch pinned buffer (1.5-2 GB/s)
-                dev = [t.to(device) for t in src]
+                if per_view:   # N copies straight from the cache slots into the [1,N,3,H,W] device tensor
+                    views = [torch.from_numpy(v) for v in s["imgs"]]
+                    imgs_dev = torch.empty((1, len(views)) + tuple(views[0].shape), dtype=torch.float32, device=device)
+                    for i, v in enumerate(views):
+                        imgs_dev[0, i].copy_(v)
+                    dev = [imgs_dev] + [t.to(device) for t in src[1:]]
+                else:
+                    dev = [t.to(device) for t in src]
                 ready = torch.cuda.Event()
                 ready.record(copy_stream)
             _tick("loader.h2d", t0)
             if decoder_pool is not None:
-                # the pageable copy above has left the shared-memory slot (the runtime staged it);
-                # what the writers need later (the reference image) is copied out before the slot is reused
+                # the pageable copies above have left the shared-memory slots (the runtime staged them);
+                # what the writers need later (the reference image) is copied out before a slot is reused
                 s = dict(s)
-                s["imgs"] = np.array(s["imgs"][:1]) if keep_ref_image else None
+                s["imgs"] = np.array(s["imgs"][0])[None] if keep_ref_image else None
             release()
             t0 = _now()
             q.put((idx, s, dev, ready))
@@ -200,8 +208,10 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
         compute = torch.cuda.current_stream(device)
         own_pool = None
         if decoder_pool is None and decoder_procs > 0:
-            from .decoder_pool import DecoderPool
-            own_pool = decoder_pool = DecoderPool(dataset, procs=decoder_procs)
+            from .decoder_pool import DecoderPool, ViewDecoderPool
+            # datasets that can decode single views (EvalDataset) get the view-level pool: each image once
+            by_view = all(hasattr(dataset, a) for a in ("view_plan", "decode_view", "assemble"))
+            own_pool = decoder_pool = (ViewDecoderPool if by_view else DecoderPool)(dataset, procs=decoder_procs)
         th = threading.Thread(target=_loader, args=(dataset, mine, device, copy_stream, q, decoders, decoder_pool,
                                                     save_images), daemon=True)
         th.start()

@@ -102,3 +102,43 @@ class _FailingDataset:
         if i == 1:
             raise KeyError("broken sample")
         return {"imgs": np.zeros((1, 3, 4, 4), np.float32), "filename": str(i)}
+
+
+def test_view_decoder_pool_decodes_every_view_once_and_matches_the_dataset(tmp_path):
+    """View-level pool: samples assembled from a shared-memory cache of decoded views equal
+    dataset[i] bit for bit, also with a cache smaller than the lookahead window wants."""
+    import os
+    from synthetic_dataset import write_synthetic_dataset
+    from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset
+    from scene_3dreconstruction_mvsnet_amd.decoder_pool import ViewDecoderPool
+    listfile = write_synthetic_dataset(str(tmp_path))
+    ds = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, "test", 3, 16, 1.06, img_res=(96, 128),
+                     dataset_name="dtu")
+    # the three-step form of a sample is the sample
+    for i in range(len(ds)):
+        want = ds[i]
+        filename, views = ds.view_plan(i)
+        dec = [ds.decode_view(p) for p, _ in views]
+        got = ds.assemble(i, [a for _, a in dec])
+        assert filename == want["filename"]
+        np.testing.assert_array_equal(np.stack([x for x, _ in dec]), want["imgs"])
+        np.testing.assert_array_equal(got["proj_matrices"], want["proj_matrices"])
+    order = list(range(len(ds))) * 3
+    with ViewDecoderPool(ds, procs=2, slots=5, lookahead=3) as pool:
+        for explicit in (True, False):
+            n = 0
+            for i, s in zip(order, pool.imap(order)):
+                want = ds[i]
+                assert s["filename"] == want["filename"] and isinstance(s["imgs"], list)
+                np.testing.assert_array_equal(np.stack(s["imgs"]), want["imgs"])
+                np.testing.assert_array_equal(s["proj_matrices"], want["proj_matrices"])
+                np.testing.assert_array_equal(s["depth_values"], want["depth_values"])
+                if explicit:
+                    pool.release(s)
+                n += 1
+            assert n == len(order)
+        name = pool._shm.name
+    assert not os.path.exists(os.path.join("/dev/shm", name.lstrip("/")))
+    with ViewDecoderPool(ds, procs=1, slots=2, lookahead=2) as small:       # fewer slots than one sample's views
+        with pytest.raises(RuntimeError, match="slots"):
+            next(small.imap([0]))
