@@ -103,6 +103,7 @@ class EvalDataset:
         # decoded-image LRU (0 = off, the reference's behaviour: every sample decodes its views again)
         self.cache_images = int(cache_images)
         self._img_cache = {} if self.cache_images > 0 else None
+        self._cam_cache = {}     # cam file -> parsed (intrinsics, extrinsics, depth_min, interval); used by assemble()
         self.datapath, self.nviews, self.ndepths = datapath, nviews, ndepths
         self.interval_scale, self.cam_subfolder, self.img_subfolder = interval_scale, cam_subfolder, img_subfolder
         self.img_res, self.dataset_name = img_res, dataset_name
@@ -143,7 +144,10 @@ class EvalDataset:
         projs, intr_list, extr_list = [], [], []
         depth_values = None
         for i, (_, cam_path) in enumerate(views):
-            intr, extr, dmin, dint = parse_cam_file(cam_path, self.interval_scale)
+            if cam_path not in self._cam_cache:
+                self._cam_cache[cam_path] = parse_cam_file(cam_path, self.interval_scale)
+            intr, extr, dmin, dint = self._cam_cache[cam_path]
+            intr, extr = intr.copy(), extr.copy()
             scale, left, top = adjust[i]
             intr[:2, :] *= scale            # the same in-place float32 updates as load_image_rescaled_cropped
             intr[0, -1] -= left

@@ -245,7 +245,10 @@ class ViewDecoderPool:
                 p.terminate()
         self._workers = []
         if self._shm is not None:
-            self._shm.close()
+            try:
+                self._shm.close()
+            except BufferError:      # the consumer still holds views of the cache (or page-locked it)
+                pass
             try:
                 self._shm.unlink()
             except FileNotFoundError:
