@@ -783,7 +783,11 @@ __global__ __launch_bounds__(256) void convg_persist_mfma_kernel(
     // tile boundaries (the next tile's first chunk is requested before this tile's last chunk of
     // MFMAs).  These layers have 1..8 chunks of only 56-224 MFMAs per wave, i.e. less than a
     // global-load round trip: as one-tile blocks every tile paid that latency in the open.
-    int goff[G::PPT], loff[G::PPT];
+    // Staging bookkeeping: the decomposition of piece p = tid + 256 i into halo coordinates (divisions by
+    // the non-power-of-two halo extents) is the same for every tile -- done once; per tile only a scalar
+    // base offset and the scalar valid ranges of (hz, hy, hx) are left (interior tiles: no masks at all).
+    int goff[G::PPT], loff[G::PPT], rel[G::PPT];
+    unsigned pos[G::PPT];   // hz | hy << 8 | hx << 16
     unsigned inside = 0;
     int ox0 = 0, oy0 = 0, oz0 = 0;
 #pragma unroll
@@ -792,7 +796,10 @@ __global__ __launch_bounds__(256) void convg_persist_mfma_kernel(
         const int half = p & 1, v = p >> 1;
         const int hx = v % G::HX, t = v / G::HX;
         const int hy = t % G::HY, hz = t / G::HY;
-        loff[i] = (p < G::NPIECE) ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS + half * 4 : -1;
+        const bool have = p < G::NPIECE;
+        loff[i] = have ? ((hz * G::HY + hy) * G::HXP + hx) * G::VS + half * 4 : -1;
+        rel[i] = have ? ((hz * Hi + hy) * Wi + hx) * 8 + half * 4 : 0;
+        pos[i] = have ? (unsigned)(hz | (hy << 8) | (hx << 16)) : 0x00FFFFFFu;
     }
 #define MVS_SETUP(TILE)                                                                             \
     {                                                                                               \
@@ -802,16 +809,24 @@ __global__ __launch_bounds__(256) void convg_persist_mfma_kernel(
         const int bz_ = b_ / nby;                                                                   \
         ox0 = bx_ * 8 * BX; oy0 = by_ * 2 * BY; oz0 = bz_ * BZ;                                     \
         const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;                          \
+        const int base_ = ((iz0 * Hi + iy0) * Wi + ix0) * 8;   /* may be negative; ok pieces are not */ \
+        const int zl = max(0, -iz0), zh = min(G::HZ - 1, Di - 1 - iz0);                             \
+        const int yl = max(0, -iy0), yh = min(G::HY - 1, Hi - 1 - iy0);                             \
+        const int xl = max(0, -ix0), xh = min(G::HX - 1, Wi - 1 - ix0);                             \
         inside = 0;                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < G::PPT; ++i) {                                        \
-            const int p = tid + i * 256;                                                            \
-            const int half = p & 1, v = p >> 1;                                                     \
-            const int hx = v % G::HX, t = v / G::HX;                                                \
-            const int hy = t % G::HY, hz = t / G::HY;                                               \
-            const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;                                  \
-            const bool ok = p < G::NPIECE && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi; \
-            goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8 + half * 4) : 0;            \
-            inside |= ok ? (1u << i) : 0u;                                                          \
+        if (zl == 0 && zh == G::HZ - 1 && yl == 0 && yh == G::HY - 1 && xl == 0 && xh == G::HX - 1) { \
+            _Pragma("unroll") for (int i = 0; i < G::PPT; ++i) {                                    \
+                const bool ok = pos[i] != 0x00FFFFFFu;                                              \
+                goff[i] = ok ? base_ + rel[i] : 0;                                                  \
+                inside |= ok ? (1u << i) : 0u;                                                      \
+            }                                                                                       \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < G::PPT; ++i) {                                    \
+                const int hz = pos[i] & 255, hy = (pos[i] >> 8) & 255, hx = (int)(pos[i] >> 16);    \
+                const bool ok = hz >= zl && hz <= zh && hy >= yl && hy <= yh && hx >= xl && hx <= xh; \
+                goff[i] = ok ? base_ + rel[i] : 0;                                                  \
+                inside |= ok ? (1u << i) : 0u;                                                      \
+            }                                                                                       \
         }                                                                                           \
     }
 

@@ -180,9 +180,10 @@ def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: i
                     pinned = _pin_pool_memory(decoder_pool)
                     views = [torch.from_numpy(v) for v in s["imgs"]]
                     imgs_dev = torch.empty((1, len(views)) + tuple(views[0].shape), dtype=torch.float32, device=device)
-                    for i, v in enumerate(views):
+                    small = [t.to(device) for t in src[1:]]   # pageable (synchronous) copies first: behind the
+                    for i, v in enumerate(views):             # asynchronous ones they would wait for them
                         imgs_dev[0, i].copy_(v, non_blocking=pinned)
-                    dev = [imgs_dev] + [t.to(device) for t in src[1:]]
+                    dev = [imgs_dev] + small
                 else:
                     dev = [t.to(device) for t in src]
                 ready = torch.cuda.Event()
