@@ -141,9 +141,10 @@ int mvs_relative_proj(const float* proj, float* rt_out, int N, void* stream) {
 
 // feats == NULL: the C8-planar feature copy (fp32, or the storage dtype when the 16-bit gather is
 // on) already sits in the workspace -- written there by FeatureNet's last layer (featnet.hip).
+// proj != NULL (and feats != NULL): `rt` is an OUTPUT, filled by an extra block of the transpose launch
 static int warp_variance_impl(const float* feats, const float* rt, const float* depth_values,
                               void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
-                              int h, int w, int dtype, void* stream) {
+                              int h, int w, int dtype, void* stream, const float* proj = nullptr) {
     if (!depth_values || !var_out || !workspace || (N > 1 && !rt))
         return fail(MVS_ERR_NULL, "mvs_warp_variance: NULL argument");
     if (int st = check_dims(N, C, D, h, w, dtype)) return st;
@@ -156,11 +157,11 @@ static int warp_variance_impl(const float* feats, const float* rt, const float* 
     float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
     if (feat16_gather() && dtype != MVS_F32) {
         if (feats)
-            if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, dtype, s)) return st;
+            if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, dtype, s, proj, const_cast<float*>(rt))) return st;
         return launch_warp_variance16(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
     }
     if (feats)
-        if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
+        if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s, proj, const_cast<float*>(rt))) return st;
     return launch_warp_variance(feats_t, rt, depth_values, var_out, N, D, h, w, dtype, s);
 }
 
@@ -277,7 +278,14 @@ static int depth_infer_impl(const float* feats, const float* proj, const float* 
     void* var = ws + W.var;
     float* cost = reinterpret_cast<float*>(ws + W.cost);
     int st;
-    if ((st = mvs_relative_proj(proj, rt, N, stream))) return st;
+    // from NCHW features the relative projections ride along with the layout transpose (one launch
+    // less); with the features already C8-planar in the workspace they get their own 1-block launch
+    static const bool no_fuse = [] {
+        const char* e = getenv("MVS_FUSE");
+        return !(e && e[0] == '1');
+    }();
+    const bool fold_proj = no_fuse && feats != nullptr && N > 1 && N <= 256;
+    if (!fold_proj && (st = mvs_relative_proj(proj, rt, N, stream))) return st;
     // CostRegNet activations live behind the variance volume; hand costreg the sub-workspace that
     // starts at act[0] laid out as for N = 1 (same relative offsets).
     const Workspace W1 = workspace_layout(1, C, D, h, w, dtype);
@@ -286,13 +294,9 @@ static int depth_infer_impl(const float* feats, const float* proj, const float* 
     // Default: materialise the variance volume and run conv0 as its own kernel -- on MI355X the two
     // separate kernels (0.29 + 0.57 ms at cfg2) beat the fused kernel (1.40 ms: one block per CU
     // cannot keep enough gathers in flight).  MVS_FUSE=1 selects the fused path.
-    static const bool no_fuse = [] {
-        const char* e = getenv("MVS_FUSE");
-        return !(e && e[0] == '1');
-    }();
     if (no_fuse || !feats) {
         if ((st = warp_variance_impl(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
-                                     h, w, dtype, stream)))
+                                     h, w, dtype, stream, fold_proj ? proj : nullptr)))
             return st;
         if ((st = costreg_impl(var, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream))) return st;
     } else {

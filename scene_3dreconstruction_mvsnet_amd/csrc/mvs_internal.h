@@ -186,7 +186,9 @@ int fail(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // kernel launchers (implemented in the .hip files); all enqueue on `s` and return a status
-int launch_nchw_to_c8(const float* in, void* out, int N, int C, int h, int w, int dtype, hipStream_t s);
+// proj/rt != NULL: the relative projections are computed by an extra block row of the same launch
+int launch_nchw_to_c8(const float* in, void* out, int N, int C, int h, int w, int dtype, hipStream_t s,
+                      const float* proj = nullptr, float* rt = nullptr);
 int launch_warp_variance16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                            int h, int w, int dtype, hipStream_t s);
 int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s);

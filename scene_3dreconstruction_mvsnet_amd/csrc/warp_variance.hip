@@ -26,50 +26,10 @@
 namespace mvs {
 
 // ---------------------------------------------------------------------------------------------
-// [N][C=32][h][w] -> C8-planar [4][N][h][w][8]; one block transposes 32 channels x 64 pixels
-// through LDS.
-// ---------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ in,
-                                                         void* __restrict__ out, int N, int hw) {
-    __shared__ float tile[32][65];
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-    const float* src = in + (size_t)n * 32 * hw;
-#pragma unroll
-    for (int c = ty; c < 32; c += 4) {
-        const int p = p0 + tx;
-        tile[c][tx] = (p < hw) ? src[(size_t)c * hw + p] : 0.0f;
-    }
-    __syncthreads();
-    const int c8 = threadIdx.x & 7, pp = threadIdx.x >> 3;  // 8 channels x 32 pixels per pass
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl)
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int q = pass * 32 + pp, p = p0 + q;
-            if (p < hw) St<DT>::store1(out, (((size_t)pl * N + n) * hw + p) * 8 + c8, tile[pl * 8 + c8][q]);
-        }
-}
-
-int launch_nchw_to_c8(const float* in, void* out, int N, int C, int h, int w, int dtype, hipStream_t s) {
-    (void)C;
-    const int hw = h * w;
-    dim3 grid((hw + 63) / 64, N);
-    if (dtype == MVS_F32) nchw_to_c8_kernel<MVS_F32><<<grid, 256, 0, s>>>(in, out, N, hw);
-    else if (dtype == MVS_F16) nchw_to_c8_kernel<MVS_F16><<<grid, 256, 0, s>>>(in, out, N, hw);
-    else if (dtype == MVS_BF16) nchw_to_c8_kernel<MVS_BF16><<<grid, 256, 0, s>>>(in, out, N, hw);
-    else return fail(MVS_ERR_BAD_DTYPE, "nchw_to_c8: unknown dtype %d", dtype);
-    return check_hip(hipGetLastError(), "nchw_to_c8 launch");
-}
-
-// ---------------------------------------------------------------------------------------------
 // rt[v-1] = rows 0..2 of proj[v] @ inverse(proj[0])      (models/module.py:107-109)
 // One thread per source view; Gauss-Jordan with partial pivoting in fp64, rounded to fp32.
 // ---------------------------------------------------------------------------------------------
-__global__ void relative_proj_kernel(const float* __restrict__ proj, float* __restrict__ rt, int N) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x + 1;
+__device__ void relative_proj_view(const float* __restrict__ proj, float* __restrict__ rt, int N, int v) {
     if (v >= N) return;
     double a[4][8];
     for (int i = 0; i < 4; ++i)
@@ -106,6 +66,58 @@ __global__ void relative_proj_kernel(const float* __restrict__ proj, float* __re
         o[i * 3 + 2] = (float)row[2];
         o[9 + i] = (float)row[3];
     }
+}
+
+__global__ void relative_proj_kernel(const float* __restrict__ proj, float* __restrict__ rt, int N) {
+    relative_proj_view(proj, rt, N, blockIdx.x * blockDim.x + threadIdx.x + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// [N][C=32][h][w] -> C8-planar [4][N][h][w][8]; one block transposes 32 channels x 64 pixels
+// through LDS.
+// ---------------------------------------------------------------------------------------------
+// proj != NULL: one extra block row (blockIdx.y == N) computes the relative projections of
+// models/module.py:107-109 on the side -- a separate 1-block launch costs 7-8 us of a 950 us map.
+template <int DT>
+__global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ in,
+                                                         void* __restrict__ out, int N, int hw,
+                                                         const float* __restrict__ proj, float* __restrict__ rt) {
+    __shared__ float tile[32][65];
+    if (blockIdx.y == (unsigned)N) {   // only launched when proj != NULL
+        if (blockIdx.x == 0) relative_proj_view(proj, rt, N, (int)threadIdx.x + 1);
+        return;
+    }
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const float* src = in + (size_t)n * 32 * hw;
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const int p = p0 + tx;
+        tile[c][tx] = (p < hw) ? src[(size_t)c * hw + p] : 0.0f;
+    }
+    __syncthreads();
+    const int c8 = threadIdx.x & 7, pp = threadIdx.x >> 3;  // 8 channels x 32 pixels per pass
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int q = pass * 32 + pp, p = p0 + q;
+            if (p < hw) St<DT>::store1(out, (((size_t)pl * N + n) * hw + p) * 8 + c8, tile[pl * 8 + c8][q]);
+        }
+}
+
+int launch_nchw_to_c8(const float* in, void* out, int N, int C, int h, int w, int dtype, hipStream_t s,
+                      const float* proj, float* rt) {
+    (void)C;
+    const int hw = h * w;
+    if (N > 256) proj = nullptr;   // the side block has one thread per source view
+    dim3 grid((hw + 63) / 64, proj ? N + 1 : N);
+    if (dtype == MVS_F32) nchw_to_c8_kernel<MVS_F32><<<grid, 256, 0, s>>>(in, out, N, hw, proj, rt);
+    else if (dtype == MVS_F16) nchw_to_c8_kernel<MVS_F16><<<grid, 256, 0, s>>>(in, out, N, hw, proj, rt);
+    else if (dtype == MVS_BF16) nchw_to_c8_kernel<MVS_BF16><<<grid, 256, 0, s>>>(in, out, N, hw, proj, rt);
+    else return fail(MVS_ERR_BAD_DTYPE, "nchw_to_c8: unknown dtype %d", dtype);
+    return check_hip(hipGetLastError(), "nchw_to_c8 launch");
 }
 
 int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s) {
