@@ -669,3 +669,23 @@ def test_save_depth_raises_when_the_completer_fails(tmp_path):
                         "filename": "scanX/{}/" + "{:0>8}".format(i) + "{}"})
     with pytest.raises(RuntimeError, match="incomplete"):
         save_depth_sharded(Broken(), samples, str(tmp_path), device=DEV, writers=1, decoders=2)
+
+
+# ------------------------------------------------------------------------------ more than one GPU
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the round's test box has one)")
+def test_two_ranks_gather_over_rccl_and_bench_self_launch():
+    """On a multi-GPU box: `python bench.py --gpus 2` launches its own ranks (one per GPU, RCCL all-gather
+    of the results inside the timed region) and prints one line for the whole job.  Skipped -- and so
+    UNMEASURED -- on the one-GPU box these tests normally run on."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-e2e", "--staged-steps", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
