@@ -9,7 +9,8 @@
 // cost is [D][h][w] fp32: consecutive lanes = consecutive pixels, so every depth row is read
 // fully coalesced.  A block owns 16 pixels; its 256 threads split D into 16 slices, each doing an
 // online softmax (running max / sum / weighted sums), merged through LDS.  HBM-bound:
-// algorithmic bytes = D*h*w*4 + 2*h*w*4.
+// algorithmic bytes = D*h*w*4 + 2*h*w*4.  The kernel is 15 us of latency, not bandwidth: a slice's
+// logits are requested eight at a time before the (dependent) exp / max chain consumes them.
 #include "mvs_internal.h"
 
 namespace mvs {
@@ -28,17 +29,25 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
     const int d0 = slice * per, d1 = min(d0 + per, D);
     float m = -INFINITY, s = 0.0f, sd = 0.0f, si = 0.0f;
     if (active) {
-        for (int d = d0; d < d1; ++d) {
-            const float c = cost[(size_t)d * hw + p];
-            if (c > m) {
-                const float r = expf(m - c);  // exp(-inf) = 0 on the first element
-                s *= r; sd *= r; si *= r;
-                m = c;
+        for (int db = d0; db < d1; db += 8) {
+            float cbuf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cbuf[j] = cost[(size_t)min(db + j, D - 1) * hw + p];   // independent loads
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = db + j;
+                if (d >= d1) break;
+                const float c = cbuf[j];
+                if (c > m) {
+                    const float r = expf(m - c);  // exp(-inf) = 0 on the first element
+                    s *= r; sd *= r; si *= r;
+                    m = c;
+                }
+                const float e = expf(c - m);
+                s += e;
+                sd = fmaf(e, dv[d], sd);
+                si = fmaf(e, (float)d, si);
             }
-            const float e = expf(c - m);
-            s += e;
-            sd = fmaf(e, dv[d], sd);
-            si = fmaf(e, (float)d, si);
         }
     }
     s_m[slice][lane] = m; s_s[slice][lane] = s; s_d[slice][lane] = sd; s_i[slice][lane] = si;
