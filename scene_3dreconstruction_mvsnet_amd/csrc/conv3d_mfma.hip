@@ -1047,21 +1047,7 @@ struct DeconvG {
     static_assert(MT % MG == 0, "block tile must split evenly over the M-groups");
 };
 
-// k-step -> (class, kz, dz, ky, dy); shared by the kernel and the host packer
-struct DeconvStep { int cls, kz, dz, ky, dy; };
-__host__ __device__ constexpr DeconvStep deconv_step(int ks) {
-    // z/y tap lists: parity 0 -> {(k=1,d=0)}; parity 1 -> {(k=2,d=0), (k=0,d=1)}
-    // ks 0: cls0 | 1,2: cls1 (py=1) | 3,4: cls2 (pz=1) | 5..8: cls3 (pz=1, py=1)
-    return ks == 0 ? DeconvStep{0, 1, 0, 1, 0}
-         : ks == 1 ? DeconvStep{1, 1, 0, 2, 0}
-         : ks == 2 ? DeconvStep{1, 1, 0, 0, 1}
-         : ks == 3 ? DeconvStep{2, 2, 0, 1, 0}
-         : ks == 4 ? DeconvStep{2, 0, 1, 1, 0}
-         : ks == 5 ? DeconvStep{3, 2, 0, 2, 0}
-         : ks == 6 ? DeconvStep{3, 2, 0, 0, 1}
-         : ks == 7 ? DeconvStep{3, 0, 1, 2, 0}
-                   : DeconvStep{3, 0, 1, 0, 1};
-}
+// deconv_step(ks) -> (class, kz, dz, ky, dy): mvs_internal.h (shared with conv11_prob.hip and the host packer)
 
 template <int DT, int CIN, int COUT, int BZ, int BY, int BX>
 __global__ __launch_bounds__(256) void deconvg_mfma_kernel(

@@ -206,6 +206,8 @@ static int costreg_impl(const void* var, const void* weights_blob, float* cost_o
     if ((st = run(6, act(5), nullptr, act(6)))) return st;     // conv6
     if ((st = run(7, act(6), act(4), act(7)))) return st;      // conv4 + conv7(x)
     if ((st = run(8, act(7), act(2), act(8)))) return st;      // conv2 + conv9(x)
+    if (conv11_prob_enabled(dtype))                            // conv0 + conv11(x) and prob in one kernel
+        return launch_conv11_prob(act(8), act(0), cost_out, blob, D >> 1, h >> 1, w >> 1, dtype, s);
     if ((st = run(9, act(8), act(0), act(9)))) return st;      // conv0 + conv11(x)
     return run(10, act(9), nullptr, cost_out);                 // prob
 }

@@ -181,6 +181,23 @@ int launch_c8_to_nchw(const float* in, float* out, int N, int C, int h, int w, h
 int launch_narrow_features(const float* in, void* out, size_t n, int dtype, hipStream_t s);
 void pack_fconv_weights(const float* w, int cin, int cout, int k, float* bp);
 
+// Transposed-convolution k-steps of the gather-form MFMA kernels (conv3d_mfma.hip, conv11_prob.hip):
+// k-step -> (output parity class 2*pz + py, kz, dz, ky, dy).  Per axis o = 2i - 1 + k: parity 0 has the
+// one tap (k=1, d=0), parity 1 the two taps (k=2, d=0) and (k=0, d=1).
+struct DeconvStep { int cls, kz, dz, ky, dy; };
+__host__ __device__ constexpr DeconvStep deconv_step(int ks) {
+    // ks 0: cls0 | 1,2: cls1 (py=1) | 3,4: cls2 (pz=1) | 5..8: cls3 (pz=1, py=1)
+    return ks == 0 ? DeconvStep{0, 1, 0, 1, 0}
+         : ks == 1 ? DeconvStep{1, 1, 0, 2, 0}
+         : ks == 2 ? DeconvStep{1, 1, 0, 0, 1}
+         : ks == 3 ? DeconvStep{2, 2, 0, 1, 0}
+         : ks == 4 ? DeconvStep{2, 0, 1, 1, 0}
+         : ks == 5 ? DeconvStep{3, 2, 0, 2, 0}
+         : ks == 6 ? DeconvStep{3, 2, 0, 0, 1}
+         : ks == 7 ? DeconvStep{3, 0, 1, 2, 0}
+                   : DeconvStep{3, 0, 1, 0, 1};
+}
+
 // thread-local error text
 int fail(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
@@ -228,6 +245,10 @@ void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp);
+// conv11 (+ conv0 skip) and prob in one kernel, fp32 storage only (conv11_prob.hip)
+int launch_conv11_prob(const void* x, const void* skip, float* cost, const float* blob, int Di, int Hi,
+                       int Wi, int dtype, hipStream_t s);
+bool conv11_prob_enabled(int dtype);
 int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, const void* panel,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out);

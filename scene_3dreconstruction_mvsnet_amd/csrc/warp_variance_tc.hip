@@ -21,6 +21,13 @@
 #include "storage.h"
 #include "warp_common.h"
 
+// Diagnostic builds (`make ablate11` .. `ablate14`, wrong results, timing only): 11 = 20 extra VALU per depth
+// step, 12 = volume stores predicated off at run time (the arithmetic stays), 13 = no re-gathers after a
+// block's first, 14 = 12 + 13.  Product builds leave MVS_ABLATE at 0.
+#ifndef MVS_ABLATE
+#define MVS_ABLATE 0
+#endif
+
 namespace mvs {
 
 namespace {
@@ -317,7 +324,16 @@ __device__ __forceinline__ void store_voxel_buf(__amdgpu_buffer_rsrc_t rs, unsig
     }
 }
 
-template <int DT, int FDT, int NV, int CPT, int NTS>
+// the lanes 4q .. 4q+3 of every 8-lane pixel group hand their value to the group's other quad
+template <int Q>
+__device__ __forceinline__ int pair_pick(int v) {
+    if constexpr (Q == 0) return __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1, 3
+    else return __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                     // row_shl:4 into banks 0, 2
+}
+template <int Q>
+__device__ __forceinline__ float pair_pick(float v) { return __int_as_float(pair_pick<Q>(__float_as_int(v))); }
+
+template <int DT, int FDT, int NV, int CPT, int NTS, int PAIR>
 __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
                                                                 const float* __restrict__ rt,
                                                                 const float* __restrict__ dv,
@@ -377,12 +393,17 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
 #pragma unroll
     for (int v = 0; v < NV; ++v) key[v] = -1;
 
-    // (re-)gather the taps of every view whose 2x2 cell differs from the cached one
-    auto regather = [&](const SampK& rec) {
+    // (re-)gather the taps of every view whose 2x2 cell differs from the cached one; lane v of each quad
+    // holds view v's cell key in `keys`
+    auto regather = [&](int keys) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int k = quad_bcast(rec.key, v);
+            const int k = quad_bcast(keys, v);
+#if MVS_ABLATE == 13 || MVS_ABLATE == 14
+            if (k != key[v] && (key[v] == -1 || slab < 0)) {
+#else
             if (k != key[v]) {   // uniform over the lanes of a pixel: they share key and cache state
+#endif
                 const unsigned o00 = (unsigned)k >> 2, dx = (unsigned)k & 1u, dyw = (k & 2) ? (unsigned)w : 0u;
                 const unsigned b00 = plane_b + o00 * (8u * FES);
                 const unsigned soff = (unsigned)(v + 1) * view_b;
@@ -395,10 +416,9 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
         }
     };
 
-    // one depth step: blend with `cur`'s weights, request `nxt`'s taps, variance + stores, evaluate `nn`
-    auto step = [&](const SampK& cur, const SampK& nxt, SampK& nn, int d) {
-        // blend + accumulate on channel pairs (v_pk_fma_f32 / v_pk_mul_f32)
-        f32x2 S[NP], Q[NP];
+    // blend the cached taps with the weights held by lane v of each quad, accumulate sum / sum of squares
+    // on channel pairs (v_pk_fma_f32 / v_pk_mul_f32)
+    auto blend = [&](float mw00, float mw01, float mw10, float mw11, f32x2 (&S)[NP], f32x2 (&Q)[NP]) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             S[j] = refp[j];
@@ -406,8 +426,8 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const float w00 = quad_bcast(cur.w00, v), w01 = quad_bcast(cur.w01, v);
-            const float w10 = quad_bcast(cur.w10, v), w11 = quad_bcast(cur.w11, v);
+            const float w00 = quad_bcast(mw00, v), w01 = quad_bcast(mw01, v);
+            const float w10 = quad_bcast(mw10, v), w11 = quad_bcast(mw11, v);
             const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -427,7 +447,8 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
         // old taps alive across them and needs a second set of tap registers (378 VGPRs + AGPRs)
 #pragma unroll
         for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(S[j]), "+v"(Q[j]));
-        if (d + 1 < d1) regather(nxt);   // wave-uniform: the slab's last step has no successor
+    };
+    auto variance_store = [&](const f32x2 (&S)[NP], const f32x2 (&Q)[NP]) {
         f32x2 o[NP];
         const f32x2 IN = {inv_n, inv_n};
 #pragma unroll
@@ -435,23 +456,70 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
             const f32x2 m = S[j] * IN;
             o[j] = __builtin_elementwise_fma(-m, m, Q[j] * IN);
         }
+#if MVS_ABLATE == 12 || MVS_ABLATE == 14
+        if (slab < 0)
+#endif
         store_voxel_buf<DT, CPT, NTS>(vrs, out_v, o);
         out_v += dstep_v;
-        nn = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d + 2, D - 1)], sx, sy, h, w);
+#if MVS_ABLATE == 11
+        asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+                     "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+                     "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+                     "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+                     : "+v"(out_v));
+#endif
     };
 
-    SampK sa = make_samp_key(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w);
-    SampK sb = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d0 + 1, D - 1)], sx, sy, h, w), sc;
-    regather(sa);
-    int d = d0;
-    for (; d + 2 < d1; d += 3) {   // three records rotate: no register copies
-        step(sa, sb, sc, d);
-        step(sb, sc, sa, d + 1);
-        step(sc, sa, sb, d + 2);
-    }
-    if (d < d1) {
-        step(sa, sb, sc, d);
-        if (d + 1 < d1) step(sb, sc, sa, d + 1);
+    if constexpr (PAIR && LPP == 8) {
+        // 8 lanes per pixel, 4 views: quad q of a pixel evaluates the projections of depth da + q, so one
+        // pass through make_samp_key serves two depth steps; the step for da + q first moves quad q's
+        // record into both quads (one DPP per field), then broadcasts lane v as before.
+        const int eq = sub >> 2;
+        auto eval = [&](int dd) {   // dd is even-aligned to the slab start; both depths' values come by scalar load
+            const float da = dv[min(dd, D - 1)], db = dv[min(dd + 1, D - 1)];
+            return make_samp_key(qx, qy, qz, tx, ty, tz, eq ? db : da, sx, sy, h, w);
+        };
+        // P holds depths da, da + 1; N receives da + 2, da + 3
+        auto pair_step = [&](const SampK& P, SampK& N, int da) {
+            f32x2 S[NP], Q[NP];
+            blend(pair_pick<0>(P.w00), pair_pick<0>(P.w01), pair_pick<0>(P.w10), pair_pick<0>(P.w11), S, Q);
+            if (da + 1 < d1) regather(pair_pick<1>(P.key));   // wave-uniform
+            variance_store(S, Q);
+            N = eval(da + 2);
+            if (da + 1 < d1) {
+                blend(pair_pick<1>(P.w00), pair_pick<1>(P.w01), pair_pick<1>(P.w10), pair_pick<1>(P.w11), S, Q);
+                if (da + 2 < d1) regather(pair_pick<0>(N.key));
+                variance_store(S, Q);
+            }
+        };
+        SampK sa = eval(d0), sb;
+        regather(pair_pick<0>(sa.key));
+        for (int d = d0; d < d1; d += 4) {   // two records alternate: no register copies
+            pair_step(sa, sb, d);
+            if (d + 2 < d1) pair_step(sb, sa, d + 2);
+        }
+    } else {
+        // one depth step: blend with `cur`'s weights, request `nxt`'s taps, variance + stores, evaluate `nn`
+        auto step = [&](const SampK& cur, const SampK& nxt, SampK& nn, int d) {
+            f32x2 S[NP], Q[NP];
+            blend(cur.w00, cur.w01, cur.w10, cur.w11, S, Q);
+            if (d + 1 < d1) regather(nxt.key);   // wave-uniform: the slab's last step has no successor
+            variance_store(S, Q);
+            nn = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d + 2, D - 1)], sx, sy, h, w);
+        };
+        SampK sa = make_samp_key(qx, qy, qz, tx, ty, tz, dv[d0], sx, sy, h, w);
+        SampK sb = make_samp_key(qx, qy, qz, tx, ty, tz, dv[min(d0 + 1, D - 1)], sx, sy, h, w), sc;
+        regather(sa.key);
+        int d = d0;
+        for (; d + 2 < d1; d += 3) {   // three records rotate: no register copies
+            step(sa, sb, sc, d);
+            step(sb, sc, sa, d + 1);
+            step(sc, sa, sb, d + 2);
+        }
+        if (d < d1) {
+            step(sa, sb, sc, d);
+            if (d + 1 < d1) step(sb, sc, sa, d + 1);
+        }
     }
 }
 
@@ -466,11 +534,17 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
         return e && e[0] == '1';
     }();
     const int df = (force_df || (size_t)N * h * w * 32 * fes > ((size_t)24 << 20)) ? 1 : 0;
+    // MVS_WARP_PAIR=0: every quad evaluates every depth's projections (A/B runs); default: one quad per depth parity
+    static const bool pair = [] {
+        const char* e = getenv("MVS_WARP_PAIR");
+        return !(e && e[0] == '0');
+    }();
     const unsigned npb = (h * w + pix - 1) / pix, nsl = (D + slab - 1) / slab;
     const dim3 grid = df ? dim3(nsl, npb) : dim3(npb, nsl);
 #define MVS_TC2(NV)                                                                                               \
-    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df); \
-    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df);
+    if (nts) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 1, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df); \
+    else if (pair) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0, CPT == 4><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df); \
+    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0, 0><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df);
     switch (N - 1) {
         case 1: MVS_TC2(1) break;
         case 2: MVS_TC2(2) break;
