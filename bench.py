@@ -61,6 +61,9 @@ def stage_costs(N, D, h, w, es=4):
         out_es = 4 if name == "prob" else es
         flops = 2.0 * 27 * ci * co * (vin if kind == "deconv" else vout)
         costs[name] = dict(bytes=ci * vin * es + co * vout * out_es + skip, flops=flops)
+    # conv11 (+ conv0 skip) and prob in one kernel: the 8-channel tensor between them never reaches HBM
+    costs["conv11_prob"] = dict(bytes=16 * (V0 >> 3) * es + 8 * V0 * es + V0 * 4,
+                                flops=costs["conv11"]["flops"] + costs["prob"]["flops"])
     costs["softargmin"] = dict(bytes=V0 * 4 + 2 * h * w * 4, flops=0.0)
     return costs
 
@@ -178,8 +181,13 @@ def main(argv=None):
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
     fused = args.fused_conv0
-    stage_names = (["relative_proj", "warp_conv0"] + [l[0] for l in LAYERS[1:]] + ["softargmin"]) if fused \
-        else (["relative_proj", "warp_variance"] + [l[0] for l in LAYERS] + ["softargmin"])
+    # the library ends the fp32 path in ONE kernel for conv11 + prob (csrc/conv11_prob.hip) unless MVS_FUSE_PROB=0
+    fused_tail = storage == "f32" and os.environ.get("MVS_FUSE_PROB") != "0"
+    layer_names = [l[0] for l in LAYERS]
+    if fused_tail:
+        layer_names = layer_names[:9] + ["conv11_prob"]
+    stage_names = (["relative_proj", "warp_conv0"] + layer_names[1:] + ["softargmin"]) if fused \
+        else (["relative_proj", "warp_variance"] + layer_names + ["softargmin"])
     n_ev = len(stage_names) + 1
     KS = max(0, args.staged_steps)      # maps of the per-kernel event pass after the timed region
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(max(K, KS))]
@@ -224,6 +232,13 @@ def main(argv=None):
             first = 0
         rec(ei)
         for li in range(first, 11):
+            if fused_tail and li == 9:
+                _lib.check(lib.mvs_conv11_prob(x.data_ptr(), B["act"][0].data_ptr(), B["cost"].data_ptr(),
+                                               blob.data_ptr(), D >> 1, h >> 1, w >> 1, dt, st))
+                x = B["cost"]
+                ei += 1
+                rec(ei)
+                break
             yb = B["cost"] if li == 10 else B["act"][li]
             sk = B["act"][skips[li]].data_ptr() if li in skips else 0
             lvin = LAYERS[li][3]

@@ -42,7 +42,7 @@ ABI_VERSION = 1
 SYMBOLS = (
     "mvs_abi_version", "mvs_last_error_string", "mvs_query_workspace", "mvs_query_weights_blob",
     "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_warp_conv0", "mvs_costreg_forward",
-    "mvs_conv_layer", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
+    "mvs_conv_layer", "mvs_conv11_prob", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
     "mvs_filter_compose", "mvs_filter_depth",
     "mvs_query_feature_blob", "mvs_pack_feature_weights", "mvs_query_feature_workspace",
     "mvs_feature_layer", "mvs_feature_net", "mvs_query_forward_workspace", "mvs_forward_images",
@@ -90,6 +90,7 @@ def load():
         lib.mvs_warp_conv0.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]
         lib.mvs_costreg_forward.argtypes = [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]
         lib.mvs_conv_layer.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
+        lib.mvs_conv11_prob.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
         lib.mvs_softargmin_conf.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]
         lib.mvs_depth_infer.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                         _i, _i, _i, _i, _i, _i, _vp]
@@ -263,6 +264,21 @@ def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
                                 y.data_ptr(), blob.data_ptr(), Di, Hi, Wi, dtype,
                                 _stream(x.device)))
     return y
+
+
+def conv11_prob(x, skip, blob):
+    """Layers 9 + 10 in one kernel: x [2,Di,Hi,Wi,8], skip [1,2Di,2Hi,2Wi,8] (fp32) -> cost logits [2Di,2Hi,2Wi]."""
+    planes, Di, Hi, Wi, c8 = x.shape
+    if planes != 2 or c8 != 8 or tuple(skip.shape) != (1, 2 * Di, 2 * Hi, 2 * Wi, 8):
+        raise RuntimeError(f"conv11_prob: shapes {tuple(x.shape)} / {tuple(skip.shape)}")
+    if x.dtype != torch.float32 or skip.dtype != torch.float32:
+        raise RuntimeError("conv11_prob: fp32 storage only")
+    if not (x.is_cuda and skip.is_cuda and x.is_contiguous() and skip.is_contiguous()):
+        raise RuntimeError("conv11_prob: needs contiguous CUDA(ROCm) tensors")
+    cost = torch.empty((2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    check(load().mvs_conv11_prob(x.data_ptr(), skip.data_ptr(), cost.data_ptr(), blob.data_ptr(), Di, Hi, Wi,
+                                 MVS_F32, _stream(x.device)))
+    return cost
 
 
 def softargmin_conf(cost, depth_values):

@@ -22,7 +22,16 @@
 //      the logits p-1, p, p+1 (taps kz = 2, 1, 0), so only the two planes just produced have to be in
 //      LDS and each of them is read once instead of three times; logit p-1 is complete after plane p.
 // Tiles overlap by one input voxel in y and x and chunks by one input plane in z (the halo is recomputed,
-// 1.35 x 1.1 of the MFMA work at cfg2).
+// 1.35 x 1.1 of the MFMA work at cfg2).  The stencil's sums are kept as (even, odd channel) pairs so that
+// its FMAs are v_pk_fma_f32 with the weights as SGPR pairs; the summation order differs from prob_lds_kernel
+// (7e-7 of the logit range at cfg2, tests/test_gpu_parity.py::test_fused_conv11_prob_matches_the_two_launches).
+//
+// Measured (profiles/r02_conv11_prob.md): 0.117-0.125 ms against 0.135-0.138 ms for the two launches.  The
+// kernel is bound by the SUM of its fp32-MFMA cycles (32 % of its SIMD time) and its vector-instruction
+// issue (23 %): on gfx950 the fp32 MFMA and the (packed) fp32 VALU share hardware -- equal peak rates -- and
+// do not overlap on a SIMD.  A producer / consumer split of the waves (MFMA waves feeding stencil waves
+// through a second tile buffer, one barrier per step) measured the same 0.120 ms and was dropped; so were
+// LDS float atomics for the skip add (+0.2 ms).
 #include "mvs_internal.h"
 #include "storage.h"
 
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
     const float* __restrict__ pw,      // prob weights [27][8]
     const float* __restrict__ pbias,   // [1]
     float* __restrict__ cost,          // [2Di][2Hi][2Wi]
-    int Di, int Hi, int Wi, int ZC, int nbx, int nby, int skew_blocks, int skew_ticks) {
+    int Di, int Hi, int Wi, int ZC, int nbx, int nby) {
     using namespace cp;
     constexpr int MPW = BY * BX / (NT / 64);       // M-tiles per wave
     constexpr int PPT = (NPIECE + NT - 1) / NT;    // staged pieces per thread
@@ -71,7 +80,6 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
     __shared__ __attribute__((aligned(16))) float in_tile[IN_FLOATS];
     __shared__ __attribute__((aligned(16))) float ct[C_FLOATS];
     __shared__ __attribute__((aligned(16))) float bpan[2 * 9 * 64 * 4];   // the whole deconv panel, staged once
-    __shared__ float dump[NT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
@@ -123,10 +131,9 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * g + e;
             const int ly = 2 * ty + (m >> 3), lx = 8 * tx + (m & 7);
-            // input voxels beyond the volume: their (meaningless) outputs land in a per-thread dump slot
-            sbase[i][e] = (iy0 + ly < Hi && ix0 + lx < Wi)
-                              ? (2 * ly + 1) * RS + (co >> 2) * HS + (2 * lx + px + 1) * 4 + (co & 3)
-                              : -1;
+            // input voxels beyond the volume scatter their (meaningless) outputs like all others: those
+            // positions lie inside the tile and the skip pass below overwrites them with zeros
+            sbase[i][e] = (2 * ly + 1) * RS + (co >> 2) * HS + (2 * lx + px + 1) * 4 + (co & 3);
         }
     }
 
@@ -292,13 +299,6 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
             if (pvalid[j]) dst[pout[j]] = s[j].x + s[j].y;
     };
 
-    // Blocks that become resident together run their phases in lockstep -- both blocks of a CU want the
-    // MFMA pipe, then both the VALU -- unless one of them starts half a step late.
-    if (skew_ticks > 0 && ((blockIdx.x / skew_blocks) & 1)) {
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)skew_ticks) __builtin_amdgcn_s_sleep(8);
-    }
-
     // ---- march ----
     const float pb = pbias[0];
     const f32x2v fresh = {pb, 0.0f};
@@ -341,10 +341,7 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
 #pragma unroll
             for (int k = 0; k < MPW; ++k)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float* dst = sbase[k][e] >= 0 ? ct + pz * PS + py * RS + sbase[k][e] : dump + tid;
-                    *dst = fmaxf(acc[c][k][e] + bv, 0.0f);
-                }
+                for (int e = 0; e < 4; ++e) ct[pz * PS + py * RS + sbase[k][e]] = fmaxf(acc[c][k][e] + bv, 0.0f);
         }
         __syncthreads();
         // ... plus the skip values, 16 bytes at a time; zeros outside the volume
@@ -422,10 +419,6 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
     if (zc_env > 0) ZC = zc_env;
     if (ZC > Di) ZC = Di;
     nzc = (Di + ZC - 1) / ZC;
-    static const int skew_ticks = [] {   // MVS_FUSE_PROB_SKEW: start delay of every other CU-load of blocks, 10 ns units
-        const char* e = getenv("MVS_FUSE_PROB_SKEW");
-        return e ? atoi(e) : 0;
-    }();
     static const int nt = [] {   // MVS_FUSE_PROB_NT=256: four waves per block (A/B runs); default 512
         const char* e = getenv("MVS_FUSE_PROB_NT");
         return (e && atoi(e) == 256) ? 256 : 512;
@@ -433,11 +426,11 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
     if (nt == 256)
         conv11_prob_kernel<MVS_F32, 256><<<nbx * nby * nzc, 256, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
                                                                          blob + L.w_off[10], blob + L.b_off[10], cost,
-                                                                         Di, Hi, Wi, ZC, nbx, nby, cus, skew_ticks);
+                                                                         Di, Hi, Wi, ZC, nbx, nby);
     else
         conv11_prob_kernel<MVS_F32, 512><<<nbx * nby * nzc, 512, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
                                                                          blob + L.w_off[10], blob + L.b_off[10], cost,
-                                                                         Di, Hi, Wi, ZC, nbx, nby, cus, skew_ticks);
+                                                                         Di, Hi, Wi, ZC, nbx, nby);
     return check_hip(hipGetLastError(), "conv11_prob launch");
 }
 

@@ -253,6 +253,16 @@ int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const vo
                              dtype, static_cast<hipStream_t>(stream));
 }
 
+int mvs_conv11_prob(const void* x, const void* skip, float* cost_out, const void* weights_blob,
+                    int Di, int Hi, int Wi, int dtype, void* stream) {
+    if (!x || !skip || !cost_out || !weights_blob) return fail(MVS_ERR_NULL, "mvs_conv11_prob: NULL argument");
+    if (dtype != MVS_F32)
+        return fail(MVS_ERR_BAD_DTYPE, "mvs_conv11_prob: fp32 storage only (dtype %d); use mvs_conv_layer 9 and 10", dtype);
+    if (Di < 1 || Hi < 1 || Wi < 1) return fail(MVS_ERR_BAD_SHAPE, "mvs_conv11_prob: input dims %d,%d,%d", Di, Hi, Wi);
+    return launch_conv11_prob(x, skip, cost_out, static_cast<const float*>(weights_blob), Di, Hi, Wi, dtype,
+                              static_cast<hipStream_t>(stream));
+}
+
 int mvs_softargmin_conf(const float* cost, const float* depth_values, float* depth_out,
                         float* conf_out, int D, int h, int w, void* stream) {
     if (!cost || !depth_values || !depth_out || !conf_out)

@@ -162,6 +162,33 @@ def test_fused_warp_conv0_matches_unfused(N, h, w, D):
                                atol=3e-4 * max(np.abs(want).max(), 1.0))
 
 
+@pytest.mark.parametrize("D,h,w", [(8, 8, 8), (8, 16, 24), (16, 32, 40), (24, 40, 72), (40, 56, 64), (16, 128, 8)])
+def test_fused_conv11_prob_matches_the_two_launches(D, h, w):
+    """mvs_conv11_prob (the tail of mvs_costreg_forward for fp32 storage) against mvs_conv_layer 9 and 10 as
+    separate kernels.  Same taps, different summation order in the stencil: equal to fp32 rounding, on
+    shapes with ragged tiles in y / x, one to three z chunks and tiles narrower than a block."""
+    sd = synthetic.random_costreg_state(seed=21)
+    blob = blob_for(sd)
+    g = torch.Generator(device="cpu").manual_seed(D * 1000 + h)
+    var = (torch.rand((4, D, h, w, 8), generator=g) * 0.5).to(DEV)
+    ws = _lib.alloc_workspace(2, 32, D, h, w, DEV)
+    a = [None] * 10
+    a[0] = _lib.conv_layer(0, var, None, blob)
+    for l in range(1, 7):
+        a[l] = _lib.conv_layer(l, a[l - 1], None, blob)
+    a[7] = _lib.conv_layer(7, a[6], a[4], blob)
+    a[8] = _lib.conv_layer(8, a[7], a[2], blob)
+    a[9] = _lib.conv_layer(9, a[8], a[0], blob)
+    want = _lib.conv_layer(10, a[9], None, blob)
+    pair = _lib.conv11_prob(a[8], a[0], blob)
+    whole = _lib.costreg_forward(var, blob, ws)
+    torch.cuda.synchronize()
+    want, pair, whole = want.cpu().numpy(), pair.cpu().numpy(), whole.cpu().numpy()
+    assert np.isfinite(pair).all()
+    np.testing.assert_allclose(pair, want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1.0))
+    np.testing.assert_array_equal(whole, pair)   # mvs_costreg_forward runs the same kernels on the same inputs
+
+
 @pytest.mark.parametrize("layer", list(range(11)))
 def test_every_layer_matches_oracle(layer):
     """mvs_conv_layer for each CostRegNet layer on random C8-planar input vs the oracle."""
@@ -283,7 +310,10 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE": "1"},           # fused warp+variance+conv0 kernel inside mvs_depth_infer
-    {"MVS_PROB_GATHER": "1"},    # prob conv with global gathers instead of the LDS tile
+    {"MVS_PROB_GATHER": "1", "MVS_FUSE_PROB": "0"},   # prob conv with global gathers instead of the LDS tile
+    {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
+    {"MVS_FUSE_PROB_NT": "256"}, # fused conv11+prob with four waves per block
+    {"MVS_FUSE_PROB_ZC": "4"},   # ... with short z chunks (many chunk seams)
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each

@@ -1,5 +1,5 @@
 # kernel-only durations of the fused conv11+prob kernel: default build and the diagnostic ablation builds
-# (make -C scene_3dreconstruction_mvsnet_amd/csrc ablate21 .. ablate24)
+# (make -C scene_3dreconstruction_mvsnet_amd/csrc ablate31 .. ablate34)
 set -e
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -11,14 +11,12 @@ run() {
   python3 - "$1" "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):
-    if 'conv11_prob' in r['Name'] or 'deconvg_mfma_kernel<0, 16, 8' in r['Name'] or 'prob_lds' in r['Name']:
-        print(sys.argv[1], r['Name'][:40], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
+    if 'conv11_prob' in r['Name']:
+        print(sys.argv[1], r['Name'][:36], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
 PY
 }
 run default
-for z in 10 12; do export MVS_FUSE_PROB_ZC=$z; run zc$z; done
-unset MVS_FUSE_PROB_ZC
-for n in 21 22 23; do
+for n in 31 32; do
   export MVS_LIB_PATH=$R/scene_3dreconstruction_mvsnet_amd/csrc/libmvs_hip_ablate$n.so
   run ablate$n
 done

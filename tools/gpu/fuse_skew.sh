@@ -1,4 +1,4 @@
-# fused conv11+prob kernel: start-delay sweep of every other CU-load of blocks (MVS_FUSE_PROB_SKEW, 10 ns units)
+# fused conv11+prob kernel: kernel-only durations per variant (environment switches of conv11_prob.hip)
 set -e
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -11,7 +11,11 @@ run() {
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):
     if 'conv11_prob' in r['Name']:
-        print(sys.argv[1], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
+        print(sys.argv[1], r['Name'][:36], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
 PY
 }
-for k in 0 300; do export MVS_FUSE_PROB_SKEW=$k; run skew$k; done
+run pc
+export MVS_FUSE_PROB_ZC=12; run pc_zc12
+export MVS_FUSE_PROB_ZC=48; run pc_zc48; unset MVS_FUSE_PROB_ZC
+export MVS_FUSE_PROB_FORM=1; run form1_nt512; unset MVS_FUSE_PROB_FORM
+bash $R/tools/gpu/fuse_pmc.sh
