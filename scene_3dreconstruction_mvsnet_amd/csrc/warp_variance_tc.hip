@@ -232,11 +232,16 @@ int launch_tc_dt(const void* feats_p, const float* rt, const float* dv, void* va
 //   * three sampling records rotate through the depth loop (this depth's weights, next depth's cell
 //     key, the projection being evaluated for d+2): no register copies.
 // Same taps, weights and fma nesting as the first form and the plain kernel: bit-identical output.
-// Measured at cfg2: 0.2345 ms (first form) -> 0.157 ms.  Tried on top and dropped: distributing the
-// sampling records through a per-wave LDS ring with one projection per two depth steps (~125 instead
-// of 155 VALU per step: 0.159 ms, no gain); non-temporal stores (slower); depth slabs of 48 / 96 (the
-// 5,120 blocks of slab 24 are exactly five rounds of the 1,024 resident blocks).  Ablations: without
-// the stores -0.055 ms, without re-gathers -0.050 ms: the three parts do not overlap yet.
+//   * with 8 lanes per pixel and at most 4 source views (PAIR): quad q of a pixel evaluates the projections
+//     of depth d + q, so one pass through make_samp_key serves two depth steps; the step for d + q moves
+//     quad q's record into both quads (one bank-masked DPP row shift per field), then broadcasts lane v as
+//     before: 136 instead of 152 VALU per wave and step.
+// Measured at cfg2: 0.2345 ms (first form) -> 0.157 ms -> 0.152 ms with the pairing.  Ablation builds
+// (make ablate11 .. ablate14, kernel only): +20 VALU per step +5 us, stores predicated off -20 us, no
+// re-gathers after a block's first -23 us, neither -36 us (0.121 ms: the vector-instruction floor).  Tried
+// on top and dropped: distributing the sampling records through a per-wave LDS ring (0.159 ms, no gain);
+// non-temporal stores (slower); depth slabs of 48 / 96 (the 5,120 blocks of slab 24 are exactly five
+// rounds of the 1,024 resident blocks).
 // ---------------------------------------------------------------------------------------------
 struct SampK {
     int key;                    // (o00 << 2) | (dy << 1) | dx : the view's clamped 2x2 cell

@@ -302,6 +302,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off)
     {"MVS_WARP_TC": "1"},        # first form of the tap-cache kernel (three re-gather paths, 8 channels per thread)
     {"MVS_WARP_CPT": "8"},       # second form with 8 channels per thread
+    {"MVS_WARP_PAIR": "0"},      # second form, every quad evaluating every depth's projections
     {"MVS_WARP_NT": "1"},        # non-temporal volume stores
     {"MVS_CONV0_WINO": "2"},     # conv0 with Winograd F(2,3) along z instead of F(4,3)
     {"MVS_WARP_LDS": "1"},       # LDS-staged warp+variance kernel

@@ -5,6 +5,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+rm -rf gpurun_out/traffic gpurun_out/stats_1stream
 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -60 gpurun_out/gpu_tests.log; exit 1; }
 tail -3 gpurun_out/gpu_tests.log
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench.err
