@@ -30,6 +30,12 @@
 // The sums are re-associated and the transform constants are not powers of two, so the result differs
 // from an fmaf chain by a few 1e-7 relative (tests bound it per layer against the oracle).
 #include "mvs_internal.h"
+
+// `make ablate49`: phase clocks (s_memtime) of the four waves of one block, printed to stderr
+// (profiles/r02_conv0_clocks.txt).  Product builds leave MVS_ABLATE at 0.
+#ifndef MVS_ABLATE
+#define MVS_ABLATE 0
+#endif
 #include "storage.h"
 
 namespace mvs {
@@ -94,8 +100,17 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
     const float* __restrict__ bw,    // [4 chunks][6 t][9 taps][2 halves][2 nt][4 j][4 k]
     const float* __restrict__ bias,  // [8]
     void* __restrict__ y,            // [D][H][W][8] storage dtype DT
-    int D, int H, int W) {
+    int D, int H, int W
+#if MVS_ABLATE == 49
+    , long long* __restrict__ dbg
+#endif
+    ) {
     using namespace c43;
+#if MVS_ABLATE == 49   // phase clocks of the four waves of one block (diagnostic build)
+#define MVS_TICK(slot) if (dbg && blockIdx.x == 2000 && (threadIdx.x & 63) == 0) dbg[(threadIdx.x >> 6) * 32 + (slot)] = clock64();
+#else
+#define MVS_TICK(slot)
+#endif
     __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + BW_FLOATS];
     float* wlds = tile + TILE_FLOATS;
 
@@ -223,19 +238,27 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
             if (tid + i * 256 < WPIECES) reinterpret_cast<f32x4*>(wlds)[tid + i * 256] = wst[i];
     };
 
+    MVS_TICK(0)
     load_chunk(0);
     store_chunk();
+    MVS_TICK(1)
     __syncthreads();
+    MVS_TICK(2)
 
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         if (c < 3) load_chunk(c + 1);
+        MVS_TICK(3 + 5 * c)
         if (wave & 1) c43_chunk_mfmas<1>(ab[0], ab[1], ab[2], wA, wB, acc);
         else c43_chunk_mfmas<0>(ab[0], ab[1], ab[2], wA, wB, acc);
+        MVS_TICK(4 + 5 * c)
         if (c < 3) {
             __syncthreads();  // every wave is done reading chunk c's planes and weights
+            MVS_TICK(5 + 5 * c)
             store_chunk();
+            MVS_TICK(6 + 5 * c)
             __syncthreads();
+            MVS_TICK(7 + 5 * c)
         }
     }
 
@@ -276,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
         const f32x4 v = __builtin_elementwise_max(o[q] + bv, zero);
         St<DT>::store4(y, (((size_t)(z0 + q) * H + gy) * W + gx) * 8 + ch * 4, v);
     }
+    MVS_TICK(24)
+#undef MVS_TICK
 }
 
 template <int DT>
@@ -283,7 +308,28 @@ static int run_conv0_w43(const void* x, void* y, const float* bw, const float* b
                          hipStream_t s) {
     using namespace c43;
     const int nb = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+#if MVS_ABLATE == 49
+    static long long* dbg = nullptr;
+    if (!dbg && hipMalloc(&dbg, 128 * sizeof(long long)) != hipSuccess) dbg = nullptr;
+    if (dbg) (void)hipMemsetAsync(dbg, 0, 128 * sizeof(long long), s);
+    conv0_w43_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bw, bias, y, D, H, W, dbg);
+    if (dbg && nb > 2000) {
+        long long h[128];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; ++w) {
+            const long long* t = h + w * 32;
+            fprintf(stderr, "conv0 wave %d: stage0 %lld bar %lld |", w, t[1] - t[0], t[2] - t[1]);
+            for (int c = 0; c < 4; ++c)
+                fprintf(stderr, " c%d: ld %lld mfma %lld bar %lld st %lld bar %lld |", c, t[3 + 5 * c] - (c ? t[2 + 5 * c] : t[2]),
+                        t[4 + 5 * c] - t[3 + 5 * c], c < 3 ? t[5 + 5 * c] - t[4 + 5 * c] : 0, c < 3 ? t[6 + 5 * c] - t[5 + 5 * c] : 0,
+                        c < 3 ? t[7 + 5 * c] - t[6 + 5 * c] : 0);
+            fprintf(stderr, " end %lld total %lld\n", t[24] - t[19], t[24] - t[0]);
+        }
+    }
+#else
     conv0_w43_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bw, bias, y, D, H, W);
+#endif
     return check_hip(hipGetLastError(), "conv0_w43_mfma launch");
 }
 
