@@ -385,6 +385,240 @@ __global__ __launch_bounds__(NT, NT / 128) void conv11_prob_kernel(   // 2nd: wa
     (void)Do;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second form: the same tile, the same step order, 512 threads -- but everything before the stencil is
+// private to a wave.  Wave w owns M-tile w (2 x 8 input voxels -> a 4 x 16 strip of both conv11 planes): it
+// stages its own 3 x 9 voxel input halo per chunk (1.4x the loads of the shared halo, L1 hits), runs its
+// 72 MFMAs, scatters and adds the skip values of its own strip -- LDS operations of one wave execute in
+// order, so none of this needs a barrier.  Two block barriers per step (tile complete / tile consumed)
+// instead of six, and the eight waves drift apart inside the producing phase instead of marching in step.
+// ---------------------------------------------------------------------------------------------
+namespace cpv {
+using namespace cp;
+constexpr int RPI = 76;                      // floats per row of a private input tile: 9 voxels + 4 (second row lands 4 banks on)
+constexpr int WIN = 2 * 3 * RPI;             // one chunk: [plane 2][row 3]
+constexpr int NPC = 2 * 27 * 2;              // 16-byte pieces of it: [plane][3 x 9 voxels][half]
+}  // namespace cpv
+
+template <int DT>
+__global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
+    const void* __restrict__ x, const float* __restrict__ bp, const float* __restrict__ bias,
+    const void* __restrict__ skip, const float* __restrict__ pw, const float* __restrict__ pbias,
+    float* __restrict__ cost, int Di, int Hi, int Wi, int ZC, int nbx, int nby) {
+    using namespace cpv;
+    __shared__ __attribute__((aligned(16))) float ct[C_FLOATS];
+    __shared__ __attribute__((aligned(16))) float win[8 * WIN];
+    __shared__ __attribute__((aligned(16))) float bpan[2 * 9 * 64 * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ix0 = bx * (IX - 1), iy0 = by * (IY - 1);
+    const int za = bz * ZC, zb = min(za + ZC, Di);
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t Vin = (size_t)Di * Hi * Wi, HWi = (size_t)Hi * Wi, HWo = (size_t)Ho * Wo;
+    const int i_first = za > 0 ? za - 1 : 0, i_last = zb < Di ? zb : Di - 1;
+
+    // ---- producer roles (wave-private) ----
+    const int tx = wave & 1, ty = wave >> 1;            // M-tile: input rows 2 ty .. +1, columns 8 tx .. +7
+    float* my = win + wave * WIN;
+    int prel[2], ploff[2];
+    unsigned pin = 0, phz = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = lane + 64 * j;
+        const int half = p & 1, v = p >> 1, hz = v / 27, vv = v % 27, hr = vv / 9, hc = vv % 9;
+        const int gy = iy0 + 2 * ty + hr, gx = ix0 + 8 * tx + hc;
+        const bool ok = p < NPC && gy < Hi && gx < Wi;
+        prel[j] = ok ? (int)((((size_t)hz * Hi + gy) * Wi + gx) * 8 + half * 4) : 0;
+        pin |= ok ? (1u << j) : 0u;
+        phz |= (hz & 1) ? (1u << j) : 0u;
+        ploff[j] = p < NPC ? (hz * 3 + hr) * RPI + hc * 8 + half * 4 : -1;
+    }
+    f32x4 pre[2];
+    bool pre_z1 = true;
+    auto load_a = [&](int i, int c) {    // raw loads; masked when they go to LDS
+        pre_z1 = i + 1 < Di;
+        const size_t base = ((size_t)c * Vin + (size_t)i * HWi) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = ((pin >> j) & 1u) && (pre_z1 || !((phz >> j) & 1u));
+            pre[j] = St<DT>::load4(x, ok ? base + prel[j] : (size_t)0);
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = ((pin >> j) & 1u) && (pre_z1 || !((phz >> j) & 1u));
+            if (ploff[j] >= 0) *reinterpret_cast<f32x4*>(my + ploff[j]) = ok ? pre[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // MFMA lane roles (deconvg_mfma_kernel): row r -> input voxel (r >> 3, r & 7) of the M-tile, g: dx = g >> 1,
+    // channels 4 (g & 1) .. + 3; column n = r -> (px, co)
+    const int r = lane & 15, g = lane >> 4;
+    const int abase = (r >> 3) * RPI + ((r & 7) + (g >> 1)) * 8 + (g & 1) * 4;
+    const int px = r >> 3, co = r & 7;
+    const float bv = bias[co];
+    // element e of the accumulators: input voxel m = 4 g + e -> tile column 8 tx + (m & 7) = 8 tx + 4 (g & 1) + e
+    const int sbase0 = (2 * (2 * ty + (g >> 1)) + 1) * RS + (co >> 2) * HS + (2 * (8 * tx + 4 * (g & 1)) + px + 1) * 4 + (co & 3);
+    // skip pieces of the wave's strip: lane -> column xx, half, row parity; j -> plane j >> 1, row 2 (j & 1) + parity
+    int srel[4], sl[4];
+    unsigned sok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = lane & 15, half = (lane >> 4) & 1, rr = 2 * (j & 1) + (lane >> 5), pz = j >> 1;
+        const int oy = 4 * ty + rr, ox = 16 * tx + xx;
+        const int gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
+        const bool ok = gy < Ho && gx < Wo;
+        srel[j] = ok ? (int)((((size_t)pz * Ho + gy) * Wo + gx) * 8 + half * 4) : 0;
+        sok |= ok ? (1u << j) : 0u;
+        sl[j] = pz * PS + (oy + 1) * RS + half * HS + (ox + 1) * 4;
+    }
+    f32x4 sk[4];
+    auto load_skip = [&](int i, bool de, bool dodd) {
+        const size_t base = (size_t)(2 * i) * HWo * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = ((sok >> j) & 1u) && ((j >> 1) ? dodd : de);
+            sk[j] = St<DT>::load4(skip, ok ? base + srel[j] : (size_t)0);   // masked when added
+        }
+    };
+    const f32x4* bsrc = reinterpret_cast<const f32x4*>(bpan) + lane;
+    f32x4 acc[4];
+    auto fetch = [&](int c, int ks, f32x4& a, f32x4& bq) {
+        const DeconvStep st = deconv_step(ks);
+        a = *reinterpret_cast<const f32x4*>(my + (st.dz * 3 + st.dy) * RPI + abase);
+        bq = bsrc[(c * 9 + ks) * 64];
+    };
+    auto mfma_step = [&](int ks, const f32x4& a, const f32x4& bq) {
+        const int cls = deconv_step(ks).cls;
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[cls], 0, 0, 0);
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[cls], 0, 0, 0);
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[cls], 0, 0, 0);
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[cls], 0, 0, 0);
+    };
+    auto mfma_chunk = [&](int c, bool de, bool dodd) {
+        if (de && dodd) {   // the usual step: operands of k-step ks + 1 requested before the MFMAs of ks
+            f32x4 a[2], bq[2];
+            fetch(c, 0, a[0], bq[0]);
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                if (ks + 1 < 9) fetch(c, ks + 1, a[(ks + 1) & 1], bq[(ks + 1) & 1]);
+                mfma_step(ks, a[ks & 1], bq[ks & 1]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                if (deconv_step(ks).cls < 2 ? !de : !dodd) continue;   // wave-uniform
+                f32x4 a, bq;
+                fetch(c, ks, a, bq);
+                mfma_step(ks, a, bq);
+            }
+        }
+    };
+
+    // ---- stencil roles: thread -> one position of the 16 x 32 tile ----
+    const int lx = tid & 31, ly = tid >> 5;
+    const int gyo = 2 * iy0 + ly, gxo = 2 * ix0 + lx;
+    const bool pvalid = gyo < Ho && gxo < Wo && (ly >= 1 || iy0 == 0) && (ly <= OY - 2 || gyo == Ho - 1) &&
+                        (lx >= 1 || ix0 == 0) && (lx <= OX - 2 || gxo == Wo - 1);
+    const size_t pout = (size_t)gyo * Wo + gxo;
+    const int cbase = ly * RS + lx * 4;   // LDS row r = tile row r - 1, x index lx = tile column lx - 1
+    auto stencil = [&](int plane, f32x2v& k2, f32x2v& k1, f32x2v& k0) {
+        const float* base = ct + plane * PS + cbase;
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {
+            f32x4 v[3][2];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    v[rr][hf] = *reinterpret_cast<const f32x4*>(base + rr * RS + hf * HS + kx * 4);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // uniform addresses: scalar loads, the weights are SGPR-pair operands of v_pk_fma_f32
+                const float* w2 = pw + ((2 * 3 + ky) * 3 + kx) * 8;
+                const float* w1 = pw + ((1 * 3 + ky) * 3 + kx) * 8;
+                const float* w0 = pw + ((0 * 3 + ky) * 3 + kx) * 8;
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    const f32x4 q = v[ky][c2 >> 1];
+                    const f32x2v d = (c2 & 1) ? (f32x2v){q.z, q.w} : (f32x2v){q.x, q.y};
+                    k2 = __builtin_elementwise_fma(d, (f32x2v){w2[2 * c2], w2[2 * c2 + 1]}, k2);
+                    k1 = __builtin_elementwise_fma(d, (f32x2v){w1[2 * c2], w1[2 * c2 + 1]}, k1);
+                    k0 = __builtin_elementwise_fma(d, (f32x2v){w0[2 * c2], w0[2 * c2 + 1]}, k0);
+                }
+            }
+        }
+    };
+    auto emit = [&](int oz, const f32x2v& sv) {
+        if (pvalid) cost[(size_t)oz * HWo + pout] = sv.x + sv.y;
+    };
+
+    const float pb = pbias[0];
+    const f32x2v fresh = {pb, 0.0f};
+    f32x2v A = fresh, B = fresh, C = fresh;
+
+    for (int k = tid; k < C_FLOATS / 4; k += 512) reinterpret_cast<f32x4*>(ct)[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 2 * 9 * 64; k += 512) reinterpret_cast<f32x4*>(bpan)[k] = reinterpret_cast<const f32x4*>(bp)[k];
+    load_skip(i_first, i_first >= za, i_first < zb);
+    load_a(i_first, 0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = i_first; i <= i_last; ++i) {
+        const bool de = i >= za, dodd = i < zb;       // even / odd conv11 plane of this step wanted
+        // ---- wave-private: stage, multiply, scatter, add the skip values ----
+        store_a();
+        load_a(i, 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_chunk(0, de, dodd);
+        store_a();                                   // after chunk 0's reads in this wave's LDS order
+        if (i < i_last) load_a(i + 1, 0);
+        mfma_chunk(1, de, dodd);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 2 ? !de : !dodd) continue;
+            float* dst = ct + (c >> 1) * PS + (c & 1) * RS + sbase0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[8 * e] = fmaxf(acc[c][e] + bv, 0.0f);
+        }
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz) {
+            if (pz ? !dodd : !de) continue;
+            f32x4 t[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) t[j] = *reinterpret_cast<const f32x4*>(ct + sl[2 * pz + j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(ct + sl[2 * pz + j]) =
+                    ((sok >> (2 * pz + j)) & 1u) ? t[j] + sk[2 * pz + j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (i < i_last) load_skip(i + 1, true, i + 1 < zb);
+        __syncthreads();
+        // ---- the whole tile: stencil ----
+        if (de) {            // even plane 2i: completes logit 2i - 1
+            stencil(0, A, B, C);
+            if (i > za) emit(2 * i - 1, A);
+        }
+        A = fresh;
+        if (dodd) {          // odd plane 2i + 1: completes logit 2i
+            stencil(1, B, C, A);
+            if (de) emit(2 * i, B);
+        }
+        const f32x2v t = A;  // (A, B, C) <- logits (2i+1, 2i+2, 2i+3)
+        A = C;
+        B = t;
+        C = fresh;
+        __syncthreads();
+    }
+    if (zb == Di) emit(Do - 1, A);   // the volume's last plane has no successor to complete it
+    (void)Do;
+}
+
 bool conv11_prob_enabled(int dtype) {   // MVS_FUSE_PROB=0: conv11 and prob as two launches (A/B runs)
     static const bool on = [] {
         const char* e = getenv("MVS_FUSE_PROB");
@@ -423,7 +657,15 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
         const char* e = getenv("MVS_FUSE_PROB_NT");
         return (e && atoi(e) == 256) ? 256 : 512;
     }();
-    if (nt == 256)
+    static const int form = [] {   // MVS_FUSE_PROB_FORM=1: shared input halo, six barriers per step (A/B runs); default 2
+        const char* e = getenv("MVS_FUSE_PROB_FORM");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    if (form == 2 && nt == 512)
+        conv11_prob_priv_kernel<MVS_F32><<<nbx * nby * nzc, 512, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
+                                                                          blob + L.w_off[10], blob + L.b_off[10], cost,
+                                                                          Di, Hi, Wi, ZC, nbx, nby);
+    else if (nt == 256)
         conv11_prob_kernel<MVS_F32, 256><<<nbx * nby * nzc, 256, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
                                                                          blob + L.w_off[10], blob + L.b_off[10], cost,
                                                                          Di, Hi, Wi, ZC, nbx, nby);

@@ -313,7 +313,8 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_FUSE": "1"},           # fused warp+variance+conv0 kernel inside mvs_depth_infer
     {"MVS_PROB_GATHER": "1", "MVS_FUSE_PROB": "0"},   # prob conv with global gathers instead of the LDS tile
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
-    {"MVS_FUSE_PROB_NT": "256"}, # fused conv11+prob with four waves per block
+    {"MVS_FUSE_PROB_FORM": "1"}, # fused conv11+prob with the shared input halo (six barriers per step)
+    {"MVS_FUSE_PROB_NT": "256"}, # ... and four waves per block
     {"MVS_FUSE_PROB_ZC": "4"},   # ... with short z chunks (many chunk seams)
 ])
 def test_optin_kernel_variants(env):

@@ -11,11 +11,9 @@ run() {
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):
     if 'conv11_prob' in r['Name']:
-        print(sys.argv[1], r['Name'][:36], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
+        print(sys.argv[1], r['Name'][:40], r['Calls'], 'avg_us', round(float(r['AverageNs']) / 1e3, 1), 'min', round(float(r['MinNs']) / 1e3, 1))
 PY
 }
-run pc
-export MVS_FUSE_PROB_ZC=12; run pc_zc12
-export MVS_FUSE_PROB_ZC=48; run pc_zc48; unset MVS_FUSE_PROB_ZC
-export MVS_FUSE_PROB_FORM=1; run form1_nt512; unset MVS_FUSE_PROB_FORM
-bash $R/tools/gpu/fuse_pmc.sh
+run form2
+export MVS_FUSE_PROB_ZC=8; run form2_zc8; unset MVS_FUSE_PROB_ZC
+export MVS_FUSE_PROB_FORM=1; run form1; unset MVS_FUSE_PROB_FORM
