@@ -1,5 +1,5 @@
 # kernel-only durations of the fused conv11+prob kernel: default build and the diagnostic ablation builds
-# (make -C scene_3dreconstruction_mvsnet_amd/csrc ablate31 .. ablate34)
+# (make -C scene_3dreconstruction_mvsnet_amd/csrc ablate21 .. ablate24; they act on the first form: MVS_FUSE_PROB_FORM=1)
 set -e
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -16,7 +16,8 @@ for r in csv.DictReader(open(sys.argv[2])):
 PY
 }
 run default
-for n in 31 32; do
+export MVS_FUSE_PROB_FORM=1
+for n in 21 22 23 24; do
   export MVS_LIB_PATH=$R/scene_3dreconstruction_mvsnet_amd/csrc/libmvs_hip_ablate$n.so
   run ablate$n
 done

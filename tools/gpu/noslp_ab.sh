@@ -1,4 +1,6 @@
-# A/B: whole library built with -fno-slp-vectorize (no compiler-made packed fp32 VALU beside the MFMAs)
+# A/B: whole library built with -fno-slp-vectorize (no compiler-made packed fp32 VALU beside the MFMAs).  Build first:
+#   make -C scene_3dreconstruction_mvsnet_amd/csrc ablate0 HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -I. -fno-slp-vectorize"
+#   mv scene_3dreconstruction_mvsnet_amd/csrc/libmvs_hip_ablate0.so scene_3dreconstruction_mvsnet_amd/csrc/libmvs_hip_noslp.so
 set -e
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
