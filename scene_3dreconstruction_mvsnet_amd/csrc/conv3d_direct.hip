@@ -523,10 +523,12 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
                 const char* p = getenv("MVS_CONV0_PAIR");
                 const char* w8 = getenv("MVS_CONV0_8W");
                 if ((e && e[0] == '0') || (p && p[0] == '1') || (w8 && w8[0] == '1')) return 0;
-                return (e && e[0] == '2') ? 2 : 4;
+                return (e && e[0] == '2') ? 2 : (e && e[0] == '6') ? 6 : 4;
             }();
             const bool fits = (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31);   // else: direct kernel (64-bit offsets)
-            if (wino == 4 && fits && Di % 4 == 0)
+            if (wino == 6 && fits && Di % 4 == 0)   // F(4,3) along z and y (conv0_wino44.hip)
+                return launch_conv0_wino44(x, y, blob + L.c0w44_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+            if (wino >= 4 && fits && Di % 4 == 0)
                 return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
             if (wino && fits)
                 return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);

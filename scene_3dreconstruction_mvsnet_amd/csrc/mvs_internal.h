@@ -46,6 +46,7 @@ struct BlobLayout {
     size_t c0w_off;                // conv0 Winograd-z panel [4][4][9][2][2][4][4] (conv0_winograd.hip)
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv0_winograd.hip)
     size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv0_wino43.hip)
+    size_t c0w44_off;              // conv0 Winograd F(4,3)-z,y panel [4][6][6][3][2][2][4][4] (conv0_wino44.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -87,6 +88,8 @@ inline BlobLayout blob_layout() {
     }
     L.c0w43_off = off;
     off += (size_t)4 * 6 * 9 * 2 * 2 * 4 * 4;
+    L.c0w44_off = off;
+    off += (size_t)4 * 6 * 6 * 3 * 2 * 2 * 4 * 4;
     L.total_floats = off;
     return L;
 }
@@ -232,6 +235,9 @@ void pack_conv0_winograd_weights(const float* wfold, float* bw);
 int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                         int dtype, hipStream_t s);
 void pack_conv0_wino43_weights(const float* wfold, float* bw);
+int launch_conv0_wino44(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
+                        int dtype, hipStream_t s);
+void pack_conv0_wino44_weights(const float* wfold, float* bw);
 int launch_convwz_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int D, int H,
                        int W, int dtype, hipStream_t s);
 void pack_convwz_weights(const float* wfold, int cin, int cout, float* bp);

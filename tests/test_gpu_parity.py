@@ -305,6 +305,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_WARP_PAIR": "0"},      # second form, every quad evaluating every depth's projections
     {"MVS_WARP_NT": "1"},        # non-temporal volume stores
     {"MVS_CONV0_WINO": "2"},     # conv0 with Winograd F(2,3) along z instead of F(4,3)
+    {"MVS_CONV0_WINO": "6"},     # conv0 with Winograd F(4,3) along z and y
     {"MVS_WARP_LDS": "1"},       # LDS-staged warp+variance kernel
     {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
     {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
