@@ -571,12 +571,17 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
     for (int i = i_first; i <= i_last; ++i) {
         const bool de = i >= za, dodd = i < zb;       // even / odd conv11 plane of this step wanted
         // ---- wave-private: stage, multiply, scatter, add the skip values ----
+        // (lanes of a wave read what other lanes of the same wave wrote: the LDS executes one wave's
+        // operations in order; wave_barrier() keeps the compiler from reordering across these points)
         store_a();
+        __builtin_amdgcn_wave_barrier();
         load_a(i, 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mfma_chunk(0, de, dodd);
+        __builtin_amdgcn_wave_barrier();
         store_a();                                   // after chunk 0's reads in this wave's LDS order
+        __builtin_amdgcn_wave_barrier();
         if (i < i_last) load_a(i + 1, 0);
         mfma_chunk(1, de, dodd);
 #pragma unroll
@@ -586,6 +591,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[8 * e] = fmaxf(acc[c][e] + bv, 0.0f);
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int pz = 0; pz < 2; ++pz) {
             if (pz ? !dodd : !de) continue;
