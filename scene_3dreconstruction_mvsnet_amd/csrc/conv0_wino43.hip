@@ -119,15 +119,19 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
     // Block -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 names the XCD: speed only,
     // never correctness) and every XCD has its own L2, so halo rows / planes shared by neighbouring
     // tiles are only re-read from L2 when the neighbours run on the SAME XCD, close in time.  Each XCD
-    // therefore owns a band of nby/8 tile rows and walks it z-fastest: consecutive blocks of an XCD
-    // share two of their six input planes, neighbouring rows follow nbz blocks later.
+    // therefore owns a band of nby/8 tile rows and walks it x-fastest, then row, then z: the XCD's ~64
+    // resident blocks form slabs of a few z tiles over the whole band, whose y / x halos are shared while
+    // they are in L2 and whose z halo (two of six planes) is re-read by the slab that follows.  Measured
+    // FETCH_SIZE per launch: 281 MB against 424 MB for z-fastest (328 MB for row-fastest, then z): with
+    // the gfx950 correction 0.69 GB = 1.10x the algorithmic 629 MB (was 1.58x); the kernel's time does not
+    // change (0.380 / 0.379 / 0.376 ms minimum in the same session) -- it is not HBM-bound.
     int bx, by, bz;
     if (nby % 8 == 0 && gridDim.x % 8 == 0) {
         const int xcd = blockIdx.x & 7, rows = nby >> 3;
         int i = blockIdx.x >> 3;
-        bz = i % nbz; i /= nbz;
+        bx = i % nbx; i /= nbx;
         by = xcd * rows + i % rows;
-        bx = i / rows;
+        bz = i / rows;
     } else {
         int b = blockIdx.x;
         bx = b % nbx; b /= nbx;
