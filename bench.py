@@ -40,6 +40,24 @@ CONFIG_NAMES = ("cfg1", "cfg2", "cfg3", "cfg5")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense (~2.5 PF; not the 2:1-sparsity figure)
+FUSED_STAGES = ("warp_conv0", "conv11_prob")   # kernels that replace two d3 stages: never part of the d3 totals
+
+
+def mfma_peak_tflops(storage, mfma16=True):
+    """MFMA peak of the arithmetic the conv layers run in: fp32 MFMA for fp32 storage (and for 16-bit storage with
+    MVS_MFMA16=0), the 16-bit matrix cores otherwise."""
+    return MFMA_F32_PEAK_TFLOPS if (storage == "f32" or not mfma16) else MFMA_16BIT_PEAK_TFLOPS
+
+
+def path_totals(costs, mfma_peak):
+    """SURVEY.md §8 d3 whole-path totals: layer by layer, no fusion credited (conv11 and prob count as two
+    stages whichever kernels ran) -> (bytes, flops, stage-wise roofline seconds)."""
+    ref = {k: v for k, v in costs.items() if k not in FUSED_STAGES}
+    b = sum(c["bytes"] for c in ref.values())
+    f = sum(c["flops"] for c in ref.values())
+    floor_s = sum(max(c["bytes"] / (HBM_PEAK_GBPS * 1e9), c["flops"] / (mfma_peak * 1e12)) for c in ref.values())
+    return b, f, floor_s
 
 LAYERS = [  # (name, cin, cout, level_in, level_out, kind)
     ("conv0", 32, 8, 0, 0, "conv"), ("conv1", 8, 16, 0, 1, "conv"), ("conv2", 16, 16, 1, 1, "conv"),
@@ -52,19 +70,20 @@ LAYERS = [  # (name, cin, cout, level_in, level_out, kind)
 def stage_costs(N, D, h, w, es=4):
     """Algorithmic bytes / FLOPs per stage per map (SURVEY.md §8 d3 definitions)."""
     V0 = D * h * w
-    costs = {"warp_variance": dict(bytes=N * 32 * h * w * 4 + 32 * V0 * es, flops=0.0),
+    # every tensor at the storage dtype (`es` bytes), as d3 defines it -- the 16-bit modes of this build keep the
+    # logits in fp32, which is more than the algorithmic bytes and is not credited
+    costs = {"warp_variance": dict(bytes=N * 32 * h * w * es + 32 * V0 * es, flops=0.0),
              # fused warp+variance+conv0: features in, 8-channel conv0 output out, conv0's FLOPs
-             "warp_conv0": dict(bytes=N * 32 * h * w * 4 + 8 * V0 * es, flops=2.0 * 27 * 32 * 8 * V0)}
+             "warp_conv0": dict(bytes=N * 32 * h * w * es + 8 * V0 * es, flops=2.0 * 27 * 32 * 8 * V0)}
     for name, ci, co, li, lo, kind in LAYERS:
         vin, vout = V0 >> (3 * li), V0 >> (3 * lo)
         skip = co * vout * es if kind == "deconv" else 0
-        out_es = 4 if name == "prob" else es
         flops = 2.0 * 27 * ci * co * (vin if kind == "deconv" else vout)
-        costs[name] = dict(bytes=ci * vin * es + co * vout * out_es + skip, flops=flops)
+        costs[name] = dict(bytes=ci * vin * es + co * vout * es + skip, flops=flops)
     # conv11 (+ conv0 skip) and prob in one kernel: the 8-channel tensor between them never reaches HBM
-    costs["conv11_prob"] = dict(bytes=16 * (V0 >> 3) * es + 8 * V0 * es + V0 * 4,
+    costs["conv11_prob"] = dict(bytes=16 * (V0 >> 3) * es + 8 * V0 * es + V0 * es,
                                 flops=costs["conv11"]["flops"] + costs["prob"]["flops"])
-    costs["softargmin"] = dict(bytes=V0 * 4 + 2 * h * w * 4, flops=0.0)
+    costs["softargmin"] = dict(bytes=V0 * es + 2 * h * w * 4, flops=0.0)
     return costs
 
 
@@ -143,6 +162,8 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic
+    # one process per GPU: keep this rank's host threads on the cores next to its GPU (before any GPU call)
+    pinned = sharding.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     # MVS_BENCH_REHEARSAL=1: run every rank on cuda:0 with the gloo backend -- a way to exercise
@@ -277,6 +298,8 @@ def main(argv=None):
         sharding.gather_maps(out, world * K, rank, world)
         torch.cuda.synchronize()
         dist.barrier()
+    per_rank = []   # seconds of the last timed pass on each rank's own clock
+
     def timed_pass():
         """EXACTLY K steps between barrier + synchronize on both sides -> seconds (max over ranks)."""
         torch.cuda.synchronize()
@@ -297,10 +320,16 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
+        own = None
         if world > 1:
-            tmax = torch.tensor([dt_s], dtype=torch.float64, device="cpu" if rehearsal else dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_s = float(tmax.item())
+            # every rank's own clock around the same region (a slow rank shows up), then the max over ranks
+            own = torch.zeros(world, dtype=torch.float64, device="cpu" if rehearsal else dev)
+            own[rank] = dt_s
+            dist.all_reduce(own, op=dist.ReduceOp.SUM)
+            own = [float(x) for x in own.tolist()]
+            dt_s = max(own)
+        per_rank.clear()
+        per_rank.extend(own or [dt_s])
         return dt_s
 
     # The K steps are timed twice.  `first_pass`: right after the W warm-up steps.  W = 5 steps are 5 ms of
@@ -311,11 +340,14 @@ def main(argv=None):
     first_elapsed = timed_pass()
     elapsed = first_elapsed
     prewarm_ms = max(0, args.prewarm_ms)
+    effective_warmup = Wm      # untimed steps in front of the pass reported as `value`
     if prewarm_ms:
         tp = time.perf_counter()
+        effective_warmup += K  # the first pass itself
         while (time.perf_counter() - tp) * 1e3 < prewarm_ms:
             for k in range(K):
                 step(k)
+            effective_warmup += K
             torch.cuda.synchronize()
         elapsed = timed_pass()
 
@@ -325,6 +357,7 @@ def main(argv=None):
     # ---- per-kernel durations: the same kernels on the same inputs through the per-stage C-ABI
     # calls, a HIP event (on the launch stream) after each, one stream, right after the timed region
     costs = stage_costs(N, D, h, w, es)
+    mfma_peak = mfma_peak_tflops(storage, os.environ.get("MVS_MFMA16") != "0")
     stages = {}
     staged_steps = list(range(KS))
     if staged_steps:
@@ -341,9 +374,9 @@ def main(argv=None):
                 ent["GBps"] = round(c["bytes"] / ms / 1e6, 1)
                 if c["flops"]:
                     ent["TFLOPs"] = round(c["flops"] / ms / 1e9, 2)
-                # fraction of this stage's own roofline: max(HBM time, fp32-MFMA time) / measured
-                floor_ms = max(c["bytes"] / (HBM_PEAK_GBPS * 1e6), c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e9))
-                ent["bound"] = "mfma" if c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e9) > c["bytes"] / (HBM_PEAK_GBPS * 1e6) else "hbm"
+                # fraction of this stage's own roofline: max(HBM time, MFMA time at the arithmetic dtype's peak) / measured
+                floor_ms = max(c["bytes"] / (HBM_PEAK_GBPS * 1e6), c["flops"] / (mfma_peak * 1e9))
+                ent["bound"] = "mfma" if c["flops"] / (mfma_peak * 1e9) > c["bytes"] / (HBM_PEAK_GBPS * 1e6) else "hbm"
                 ent["frac"] = round(floor_ms / ms, 3)
             stages[name] = ent
     roofline = None
@@ -355,12 +388,12 @@ def main(argv=None):
         dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
         c, ms = costs[dom], stages[dom]["ms"]
         t_hbm = c["bytes"] / (HBM_PEAK_GBPS * 1e9)
-        t_mfma = c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        t_mfma = c["flops"] / (mfma_peak * 1e12)
         if t_mfma > t_hbm:
             ach = c["flops"] / ms / 1e9
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3),
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": round(ach / mfma_peak, 4), "traffic": None,
                         "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
                         "algorithmic_bytes": c["bytes"]}
             if dom == "conv0" and storage == "f32" and wino in ("2", "4"):
@@ -397,11 +430,7 @@ def main(argv=None):
 
     # whole-path totals follow SURVEY.md §8 d3 (layer-by-layer, no fusion credited), independent of
     # which kernels ran
-    ref_costs = {k: v for k, v in costs.items() if k != "warp_conv0"}
-    path_bytes = sum(c["bytes"] for c in ref_costs.values())
-    path_flops = sum(c["flops"] for c in ref_costs.values())
-    stagewise_floor_s = sum(max(c["bytes"] / (HBM_PEAK_GBPS * 1e9),
-                                c["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)) for c in ref_costs.values())
+    path_bytes, path_flops, stagewise_floor_s = path_totals(costs, mfma_peak)
 
     # ---- CPU baseline (rank 0, N=1): the oracle on one full map of the same workload ---------
     cpu_baseline = None
@@ -465,7 +494,8 @@ def main(argv=None):
             "metric": "depth maps/sec at N=5 views, 640x512, D=192; achieved HBM GB/s"
                       if args.config == "cfg2" else f"depth maps/sec ({args.config})",
             "value": round(maps_per_s, 3), "unit": "depth maps/s", "n_gpus": world, "steps": K,
-            "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": Wm, "effective_warmup_steps": effective_warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if storage == "f32" else (
                 f"{storage} storage, f32 MFMA arithmetic" if os.environ.get("MVS_MFMA16") == "0"
@@ -493,6 +523,9 @@ def main(argv=None):
             "path": {"algorithmic_bytes": path_bytes, "algorithmic_flops": path_flops,
                      "stagewise_roofline_ms": round(stagewise_floor_s * 1e3, 4),
                      "frac_of_stagewise_roofline": round(stagewise_floor_s / (elapsed / K), 4)},
+            "per_rank": {"maps_per_s": [round(K / t, 2) for t in per_rank], "host_cores": len(pinned) or None,
+                         "note": "each rank's K maps / its own clock around the timed region (barriers and the "
+                                 "gather included); `value` = world*K / the slowest"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "end_to_end": end_to_end, "stages": stages,
             "parity_rel_l1_vs_oracle": parity,
         }

@@ -49,3 +49,70 @@ def gather_maps(local: torch.Tensor, n_units: int, rank: int, world: int, group=
         idx = shard_units(n_units, r, world)
         out[idx] = gathered[r * kp: r * kp + len(idx)]
     return out
+
+
+# ---------------------------------------------------------------------------- host-core affinity
+# One process per GPU: each rank's host threads (launch thread, decoder pool, PFM writers) should sit on
+# the cores of the NUMA node its GPU hangs off -- the counterpart of nothing in the reference
+# (nn.DataParallel, eval.py:309, is one process), needed because 8 ranks otherwise wander over both sockets.
+
+def _parse_cpulist(text: str) -> list:
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(sysfs_root: str = "/sys") -> list:
+    """`local_cpulist` of every AMD display/accelerator PCI function, in PCI bus order (the order HIP
+    enumerates devices in by default).  Reads sysfs only -- no HIP call, safe before a fork/exec."""
+    import glob
+    import os
+    out = []
+    for dev in sorted(glob.glob(os.path.join(sysfs_root, "bus/pci/devices/*"))):
+        try:
+            with open(os.path.join(dev, "vendor")) as f:
+                vendor = f.read().strip()
+            with open(os.path.join(dev, "class")) as f:
+                cls = int(f.read().strip(), 16) >> 16
+            if vendor != "0x1002" or cls not in (0x03, 0x12):   # display controller / processing accelerator
+                continue
+            with open(os.path.join(dev, "local_cpulist")) as f:
+                out.append(_parse_cpulist(f.read()))
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def rank_cpus(local_rank: int, local_world: int, allowed: list, gpu_cpus: list | None = None) -> list:
+    """Host cores for `local_rank` of `local_world` ranks on this node: the allowed cores local to its GPU,
+    split evenly among the ranks whose GPUs share those cores; a contiguous 1/local_world slice of the
+    allowed cores when the topology is unknown (or does not list that many GPUs)."""
+    allowed = sorted(allowed)
+    if not (0 <= local_rank < local_world):
+        raise ValueError(f"local rank {local_rank} outside {local_world}")
+    if gpu_cpus and len(gpu_cpus) >= local_world:
+        mine = sorted(set(gpu_cpus[local_rank]) & set(allowed))
+        peers = [r for r in range(local_world) if sorted(set(gpu_cpus[r]) & set(allowed)) == mine]
+        if mine and len(mine) >= len(peers):
+            i, n = peers.index(local_rank), len(peers)
+            return mine[i * len(mine) // n:(i + 1) * len(mine) // n]
+    n = len(allowed)
+    if n < local_world:
+        return allowed
+    return allowed[local_rank * n // local_world:(local_rank + 1) * n // local_world]
+
+
+def pin_rank(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> list:
+    """Pin the calling process to its rank's cores (call BEFORE the first GPU call so that the runtime's
+    helper threads inherit the mask).  Returns the cores; [] when the platform has no affinity API."""
+    import os
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return []
+    cpus = rank_cpus(local_rank, local_world, sorted(os.sched_getaffinity(0)), gpu_local_cpus(sysfs_root))
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus

@@ -388,6 +388,26 @@ def test_bench_self_launch_command_and_defaults():
         "scene_3dreconstruction_mvsnet_amd.synthetic", fromlist=["CONFIGS"]).CONFIGS)
 
 
+def test_bench_path_totals_equal_survey_d3():
+    """algorithmic bytes / FLOPs per map, layer by layer, no fusion credited -- whichever
+    kernels ran (conv11 + prob count once, not again as the fused `conv11_prob` stage)."""
+    bench = _bench()
+    want = {  # (N, D, h, w, storage): (GB, GFLOP) as SURVEY §8 d3 prints them
+        (3, 48, 32, 40, "f32"): (0.0310, 1.25), (5, 192, 128, 160, "f32"): (1.9636, 79.84),
+        (5, 256, 296, 400, "bf16"): (7.556, 615.4), (4, 192, 128, 160, "f16"): (0.9806, 79.84)}
+    for (N, D, h, w, st), (gb, gf) in want.items():
+        costs = bench.stage_costs(N, D, h, w, 4 if st == "f32" else 2)
+        b, f, floor_s = bench.path_totals(costs, bench.mfma_peak_tflops(st))
+        assert abs(b / 1e9 - gb) < 6e-4 * max(1, gb), (st, b)
+        assert abs(f / 1e9 - gf) < 6e-3 * max(1, gf / 10), (st, f)
+        if st != "f32":   # priced against the 16-bit matrix peak the big stages are HBM-bound (conv0: 3.5x)
+            assert costs["conv0"]["bytes"] / 8e12 > costs["conv0"]["flops"] / (bench.mfma_peak_tflops(st) * 1e12)
+    costs = bench.stage_costs(5, 192, 128, 160, 4)
+    b, f, floor_s = bench.path_totals(costs, bench.mfma_peak_tflops("f32"))
+    assert b == 1_963_622_400 and abs(floor_s * 1e3 - 0.5948) < 1e-4
+    assert bench.mfma_peak_tflops("f16", mfma16=False) == bench.MFMA_F32_PEAK_TFLOPS
+
+
 def test_bench_parent_of_a_multi_gpu_run_never_loads_torch(tmp_path):
     """`python bench.py --gpus 2` without torchrun: the parent only relays; it must not initialise
     HIP (it must not even import torch) before starting the ranks."""
@@ -428,3 +448,31 @@ def test_in_image_fraction():
     assert synthetic.in_image_fraction(far, dv, h, w) == 0.0
     f = synthetic.in_image_fraction(synthetic.cameras(5, h, w), dv, h, w)
     assert 0.5 < f < 1.0
+
+
+# ---------------------------------------------------------------------- rank -> host cores
+def test_rank_cpus_follow_the_gpu_numa_node(tmp_path):
+    from scene_3dreconstruction_mvsnet_amd import sharding
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # fake sysfs: 4 GPUs, two per socket, plus a NIC and an AMD non-GPU function that must be skipped
+    devs = {"0000:05:00.0": ("0x1002", "0x038000", "0-7,16-23"), "0000:15:00.0": ("0x1002", "0x038000", "0-7,16-23"),
+            "0000:85:00.0": ("0x1002", "0x120000", "8-15,24-31"), "0000:95:00.0": ("0x1002", "0x120000", "8-15,24-31"),
+            "0000:01:00.0": ("0x15b3", "0x020000", "0-7"), "0000:02:00.0": ("0x1002", "0x060400", "0-7")}
+    for name, (vendor, cls, cpus) in devs.items():
+        d = tmp_path / "bus/pci/devices" / name
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    gpus = sharding.gpu_local_cpus(str(tmp_path))
+    assert len(gpus) == 4 and gpus[0] == list(range(8)) + list(range(16, 24))
+    allowed = list(range(32))
+    got = [sharding.rank_cpus(r, 4, allowed, gpus) for r in range(4)]
+    assert got[0] == [0, 1, 2, 3, 4, 5, 6, 7] and got[1] == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert set(got[2]) | set(got[3]) == set(range(8, 16)) | set(range(24, 32))
+    assert all(not (set(a) & set(b)) for i, a in enumerate(got) for b in got[i + 1:])   # disjoint
+    # unknown topology (or a cgroup that hides the GPU's cores): contiguous slices of what is allowed
+    assert sharding.rank_cpus(1, 2, [4, 5, 6, 7], None) == [6, 7]
+    assert sharding.rank_cpus(0, 4, [40, 41, 42, 43], gpus) == [40]
+    assert sharding.rank_cpus(3, 8, [0, 1], None) == [0, 1]       # fewer cores than ranks: share them
+    assert sharding.pin_rank(0, 1) == []                          # a single rank is never pinned
