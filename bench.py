@@ -41,7 +41,7 @@ CONFIG_NAMES = ("cfg1", "cfg2", "cfg3", "cfg5")
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense (~2.5 PF; not the 2:1-sparsity figure)
-FUSED_STAGES = ("warp_conv0", "conv11_prob")   # kernels that replace two d3 stages: never part of the d3 totals
+FUSED_STAGES = ("conv11_prob",)   # kernels that replace two d3 stages: never part of the d3 totals
 
 
 def mfma_peak_tflops(storage, mfma16=True):
@@ -72,9 +72,7 @@ def stage_costs(N, D, h, w, es=4):
     V0 = D * h * w
     # every tensor at the storage dtype (`es` bytes), as d3 defines it -- the 16-bit modes of this build keep the
     # logits in fp32, which is more than the algorithmic bytes and is not credited
-    costs = {"warp_variance": dict(bytes=N * 32 * h * w * es + 32 * V0 * es, flops=0.0),
-             # fused warp+variance+conv0: features in, 8-channel conv0 output out, conv0's FLOPs
-             "warp_conv0": dict(bytes=N * 32 * h * w * es + 8 * V0 * es, flops=2.0 * 27 * 32 * 8 * V0)}
+    costs = {"warp_variance": dict(bytes=N * 32 * h * w * es + 32 * V0 * es, flops=0.0)}
     for name, ci, co, li, lo, kind in LAYERS:
         vin, vout = V0 >> (3 * li), V0 >> (3 * lo)
         skip = co * vout * es if kind == "deconv" else 0
@@ -104,9 +102,6 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams to round-robin independent maps over (each has its own workspace); two maps "
                          "in flight fill the launch gaps and the tails of the small U-Net layers (+6 %% over 1)")
-    ap.add_argument("--fused-conv0", action="store_true",
-                    help="staged pass: use the fused mvs_warp_conv0 kernel (variance volume never "
-                         "materialised) instead of separate warp+variance and conv0 kernels")
     ap.add_argument("--staged-steps", type=int, default=10,
                     help="maps of the per-kernel pass after the timed region (per-stage C-ABI calls with a "
                          "HIP event after each kernel); 0 = skip it (no `stages` / `roofline` objects)")
@@ -204,14 +199,12 @@ def main(argv=None):
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
-    fused = args.fused_conv0
     # the library ends the fp32 path in ONE kernel for conv11 + prob (csrc/conv11_prob.hip) unless MVS_FUSE_PROB=0
     fused_tail = storage == "f32" and os.environ.get("MVS_FUSE_PROB") != "0"
     layer_names = [l[0] for l in LAYERS]
     if fused_tail:
         layer_names = layer_names[:9] + ["conv11_prob"]
-    stage_names = (["relative_proj", "warp_conv0"] + layer_names[1:] + ["softargmin"]) if fused \
-        else (["relative_proj", "warp_variance"] + layer_names + ["softargmin"])
+    stage_names = ["relative_proj", "warp_variance"] + layer_names + ["softargmin"]
     n_ev = len(stage_names) + 1
     KS = max(0, args.staged_steps)      # maps of the per-kernel event pass after the timed region
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(max(K, KS))]
@@ -242,20 +235,12 @@ def main(argv=None):
         _lib.check(lib.mvs_relative_proj(proj.data_ptr(), B["rt"].data_ptr(), N, st))
         rec(1)
         ei = 2
-        if fused:
-            _lib.check(lib.mvs_warp_conv0(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
-                                          blob.data_ptr(), B["act"][0].data_ptr(), ws.data_ptr(),
-                                          ws.numel(), N, 32, D, h, w, dt, st))
-            x = B["act"][0]
-            first = 1
-        else:
-            _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
-                                             B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D,
-                                             h, w, dt, st))
-            x = B["var"]
-            first = 0
+        _lib.check(lib.mvs_warp_variance(feats.data_ptr(), B["rt"].data_ptr(), dv.data_ptr(),
+                                         B["var"].data_ptr(), ws.data_ptr(), ws.numel(), N, 32, D,
+                                         h, w, dt, st))
+        x = B["var"]
         rec(ei)
-        for li in range(first, 11):
+        for li in range(11):
             if fused_tail and li == 9:
                 _lib.check(lib.mvs_conv11_prob(x.data_ptr(), B["act"][0].data_ptr(), B["cost"].data_ptr(),
                                                blob.data_ptr(), D >> 1, h >> 1, w >> 1, dt, st))
@@ -281,7 +266,7 @@ def main(argv=None):
 
     # Timed steps: one mvs_depth_infer call per map (what the drop-in's forward enqueues), maps
     # round-robin over the S streams (each stream has its own workspace).
-    step_one = step_staged if (args.staged_timed or fused) else step_fused
+    step_one = step_staged if args.staged_timed else step_fused
 
     def step(k, ev=None):
         if S == 1:
@@ -381,8 +366,7 @@ def main(argv=None):
             stages[name] = ent
     roofline = None
     # which conv0 kernel the library picks (csrc/conv3d_direct.hip): F(4,3) unless told otherwise
-    wino = "0" if (os.environ.get("MVS_CONV0_WINO") == "0" or os.environ.get("MVS_CONV0_PAIR") == "1"
-                   or os.environ.get("MVS_CONV0_8W") == "1") else \
+    wino = "0" if os.environ.get("MVS_CONV0_WINO") == "0" else \
         ("2" if os.environ.get("MVS_CONV0_WINO") == "2" or D % 4 else "4")
     if stages:
         dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
@@ -512,7 +496,6 @@ def main(argv=None):
                                 "calls with HIP events, after the timed region" if KS else ""),
                        "in_image_frac": in_image_frac,
                        "prewarm_ms": prewarm_ms,
-                       "warp_conv0": "fused kernel" if (fused or os.environ.get("MVS_FUSE") == "1") else "separate kernels",
                        "streams": S},
             "first_pass": {"value": round(world * K / first_elapsed, 3), "ms_per_step": round(first_elapsed / K * 1e3, 4),
                            "note": f"the same {K} steps timed right after the {Wm} warm-up steps, before the device "

@@ -91,17 +91,6 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
                       void* var_out, void* workspace, size_t workspace_bytes, int N, int C, int D,
                       int h, int w, int dtype, void* stream);
 
-/* Fused homography warp + variance + conv0 (CostRegNet's first layer): the 32-channel variance
- * volume is produced plane by plane in LDS and consumed by the conv0 MFMAs in the same kernel,
- * never written to HBM.  Replaces models/module.py:96-139, models/mvsnet.py:145-177 and conv0
- * (models/mvsnet.py:36,65).  Correct but currently slower than mvs_warp_variance + conv0 as two
- * kernels, so mvs_depth_infer uses it only when MVS_FUSE=1 is set in the environment.
- *   feats, rt, depth_values as for mvs_warp_variance; weights_blob the packed blob
- *   conv0_out   dev C8-planar [1][D][h][w][8] in `dtype` (input of mvs_conv_layer(1, ...)) */
-int mvs_warp_conv0(const float* feats, const float* rt, const float* depth_values,
-                   const void* weights_blob, void* conv0_out, void* workspace, size_t workspace_bytes,
-                   int N, int C, int D, int h, int w, int dtype, void* stream);
-
 /* 3D U-Net cost regularisation.  Replaces CostRegNet.forward, models/mvsnet.py:64-73.
  *   var           dev C8-planar [4][D][h][w][8] in `dtype` (from mvs_warp_variance)
  *   weights_blob  dev copy of the mvs_pack_weights blob

@@ -41,7 +41,7 @@ ABI_VERSION = 1
 # every symbol include/mvs_abi.h declares
 SYMBOLS = (
     "mvs_abi_version", "mvs_last_error_string", "mvs_query_workspace", "mvs_query_weights_blob",
-    "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_warp_conv0", "mvs_costreg_forward",
+    "mvs_pack_weights", "mvs_relative_proj", "mvs_warp_variance", "mvs_costreg_forward",
     "mvs_conv_layer", "mvs_conv11_prob", "mvs_softargmin_conf", "mvs_depth_infer", "mvs_homo_warp", "mvs_depth_regression",
     "mvs_filter_compose", "mvs_filter_depth",
     "mvs_query_feature_blob", "mvs_pack_feature_weights", "mvs_query_feature_workspace",
@@ -87,7 +87,6 @@ def load():
                                          ctypes.c_float, _vp, _sz]
         lib.mvs_relative_proj.argtypes = [_vp, _vp, _i, _vp]
         lib.mvs_warp_variance.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]
-        lib.mvs_warp_conv0.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]
         lib.mvs_costreg_forward.argtypes = [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]
         lib.mvs_conv_layer.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
         lib.mvs_conv11_prob.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]
@@ -213,19 +212,6 @@ def warp_variance(feats, rt, depth_values, workspace, dtype=MVS_F32):
                                    var.data_ptr(), workspace.data_ptr(), workspace.numel(),
                                    N, C, D, h, w, dtype, _stream(feats.device)))
     return var
-
-
-def warp_conv0(feats, rt, depth_values, blob, workspace, dtype=MVS_F32):
-    """Fused warp + variance + conv0: feats [N,32,h,w] -> conv0 output C8-planar [1,D,h,w,8]."""
-    feats = _dev_f32(feats, "features")
-    N, C, h, w = feats.shape
-    D = depth_values.shape[0]
-    y = torch.empty((1, D, h, w, 8), dtype=TORCH_DTYPES[dtype], device=feats.device)
-    check(load().mvs_warp_conv0(feats.data_ptr(), rt.data_ptr(),
-                                _dev_f32(depth_values, "depth_values").data_ptr(), blob.data_ptr(),
-                                y.data_ptr(), workspace.data_ptr(), workspace.numel(), N, C, D, h, w,
-                                dtype, _stream(feats.device)))
-    return y
 
 
 def costreg_forward(var, blob, workspace, dtype=MVS_F32):

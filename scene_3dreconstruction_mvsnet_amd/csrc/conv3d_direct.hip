@@ -220,60 +220,9 @@ static int run_deconv(const void* x, const void* skip, void* y, const float* wgt
 }
 
 // ---------------------------------------------------------------------------------------------
-// prob: Conv3d 8 -> 1 with bias, no BN / ReLU (models/mvsnet.py:62,72).  A thread produces the
-// logits of ZPT z-adjacent voxels at one (y, x): lanes stay on x-adjacent voxels (coalesced
-// 32-byte loads, 4-byte stores) while each staged voxel feeds up to 3 outputs from registers:
-// (ZPT+2)*9 voxel loads per ZPT outputs instead of 27 per output.
-//   x [1][D][H][W][8] -> y [D][H][W]
-// ---------------------------------------------------------------------------------------------
-constexpr int kProbZPT = 4;
-
-__global__ __launch_bounds__(256) void prob_conv_kernel(const float* __restrict__ x,
-                                                        const float* __restrict__ wgt,  // [27][8][1]
-                                                        const float* __restrict__ bias,
-                                                        float* __restrict__ y, int D, int H, int W) {
-    const size_t hw = (size_t)H * W;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nzb = (D + kProbZPT - 1) / kProbZPT;
-    if (t >= hw * nzb) return;
-    const int ox = (int)(t % W), oy = (int)((t / W) % H), oz0 = (int)(t / hw) * kProbZPT;
-    float acc[kProbZPT];
-    const float bv = bias[0];
-#pragma unroll
-    for (int j = 0; j < kProbZPT; ++j) acc[j] = bv;
-#pragma unroll
-    for (int c = 0; c < kProbZPT + 2; ++c) {  // input planes oz0-1 .. oz0+ZPT
-        const int iz = oz0 + c - 1;
-        if (iz < 0 || iz >= D) continue;
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = oy + kh - 1;
-            if (iy < 0 || iy >= H) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ix = ox + kw - 1;
-                if (ix < 0 || ix >= W) continue;
-                const float* xp = x + (((size_t)iz * H + iy) * W + ix) * 8;
-                const float4 a = *reinterpret_cast<const float4*>(xp);
-                const float4 b = *reinterpret_cast<const float4*>(xp + 4);
-#pragma unroll
-                for (int j = 0; j < kProbZPT; ++j) {
-                    const int kd = c - j;  // input plane c feeds output j through tap kd
-                    if (kd < 0 || kd > 2) continue;
-                    const float* wv = wgt + (size_t)((kd * 3 + kh) * 3 + kw) * 8;
-                    acc[j] = fmaf(a.x, wv[0], fmaf(a.y, wv[1], fmaf(a.z, wv[2], fmaf(a.w, wv[3], acc[j]))));
-                    acc[j] = fmaf(b.x, wv[4], fmaf(b.y, wv[5], fmaf(b.z, wv[6], fmaf(b.w, wv[7], acc[j]))));
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kProbZPT; ++j)
-        if (oz0 + j < D) y[(size_t)(oz0 + j) * hw + (size_t)oy * W + ox] = acc[j];
-}
-
-// ---------------------------------------------------------------------------------------------
 // prob through LDS: a block stages the 6 x 10 x 34 halo tile of the 8-channel input once and
-// produces a 4 x 8 x 32 tile of logits (4 z-adjacent outputs per thread).  The global-gather
-// version above is bound by the vector-L1 path (every voxel is fetched up to 27 times); here
+// produces a 4 x 8 x 32 tile of logits (4 z-adjacent outputs per thread).  A global-gather form
+// is bound by the vector-L1 path (every voxel is fetched up to 27 times); here
 // each voxel is fetched ~2x (halo) and the 54 taps per thread come from LDS.  The two 16-byte
 // halves of a voxel are swapped for odd groups of 8 x positions so that the 32-byte voxel
 // stride stays conflict-free for ds_read_b128.
@@ -423,33 +372,19 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
 
 static int run_prob(const void* x, void* y, const float* wgt, const float* bias, int D, int H, int W,
                     int dtype, hipStream_t s) {
-    static const bool use_gather = [] {  // MVS_PROB_GATHER=1: the global-gather kernel (A/B runs)
-        const char* e = getenv("MVS_PROB_GATHER");
-        return e && e[0] == '1';
-    }();
-    if (!use_gather || dtype != MVS_F32) {
-        using namespace pl;
-        const int ntiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
-        // persistent grid: two blocks per CU (65 KB of LDS each); MVS_PROB_PERSIST=0 = one tile per block
-        static const bool persist = [] {
-            const char* e = getenv("MVS_PROB_PERSIST");
-            return !(e && e[0] == '0');
-        }();
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-        const int nb = persist ? (ntiles < 2 * cus ? ntiles : 2 * cus) : ntiles;
-        float* yo = static_cast<float*>(y);
-        if (dtype == MVS_F32) prob_lds_kernel<MVS_F32><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
-        else if (dtype == MVS_F16) prob_lds_kernel<MVS_F16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
-        else prob_lds_kernel<MVS_BF16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
-        return check_hip(hipGetLastError(), "prob_lds launch");
-    }
-    const size_t nthreads = (size_t)H * W * ((D + kProbZPT - 1) / kProbZPT);
-    prob_conv_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(
-        static_cast<const float*>(x), wgt, bias, static_cast<float*>(y), D, H, W);
-    return check_hip(hipGetLastError(), "prob_conv launch");
+    using namespace pl;
+    const int ntiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+    // persistent grid: two blocks per CU (65 KB of LDS each), next tile requested under this tile's FMAs
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int nb = ntiles < 2 * cus ? ntiles : 2 * cus;
+    float* yo = static_cast<float*>(y);
+    if (dtype == MVS_F32) prob_lds_kernel<MVS_F32><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
+    else if (dtype == MVS_F16) prob_lds_kernel<MVS_F16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
+    else prob_lds_kernel<MVS_BF16><<<nb, 256, 0, s>>>(x, wgt, bias, yo, D, H, W);
+    return check_hip(hipGetLastError(), "prob_lds launch");
 }
 
 template <int CIN, int COUT, int CPT, int STRIDE, bool DECONV, bool RELU, bool SKIP>
@@ -513,28 +448,20 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
     if (mfma16 && (dtype == MVS_F16 || dtype == MVS_BF16) && layer <= 9)
         return launch_layer_mfma16(layer, x, skip, y, blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][layer],
                                    blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
-    if (layer == 0)
-{
-            // conv0: Winograd along z on the 4x4x1 MFMA -- F(4,3) (1/2 of the direct form's MFMAs, default)
-            // or F(2,3) (2/3; MVS_CONV0_WINO=2) -- unless MVS_CONV0_WINO=0 or one of the direct variants
-            // is requested
-            static const int wino = [] {
-                const char* e = getenv("MVS_CONV0_WINO");
-                const char* p = getenv("MVS_CONV0_PAIR");
-                const char* w8 = getenv("MVS_CONV0_8W");
-                if ((e && e[0] == '0') || (p && p[0] == '1') || (w8 && w8[0] == '1')) return 0;
-                return (e && e[0] == '2') ? 2 : (e && e[0] == '6') ? 6 : 4;
-            }();
-            const bool fits = (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31);   // else: direct kernel (64-bit offsets)
-            if (wino == 6 && fits && Di % 4 == 0)   // F(4,3) along z and y (conv0_wino44.hip)
-                return launch_conv0_wino44(x, y, blob + L.c0w44_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
-            if (wino >= 4 && fits && Di % 4 == 0)
-                return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
-            if (wino && fits)
-                return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
-            return launch_conv0_mfma(x, y, blob + L.c0p_off, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi,
-                                 dtype, s);
-        }
+    if (layer == 0) {
+        // conv0: Winograd along z on the 4x4x1 MFMA -- F(4,3) (1/2 of the direct form's MFMAs, default) or
+        // F(2,3) (2/3; MVS_CONV0_WINO=2) -- unless MVS_CONV0_WINO=0 asks for the direct form
+        static const int wino = [] {
+            const char* e = getenv("MVS_CONV0_WINO");
+            return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 4;
+        }();
+        const bool fits = (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31);   // else: direct kernel (64-bit offsets)
+        if (wino >= 4 && fits && Di % 4 == 0)
+            return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+        if (wino && fits)
+            return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+        return launch_conv0_mfma(x, y, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+    }
     if (layer == 2 || layer == 4) {
         // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv0_winograd.hip) unless
         // MVS_CONV_WINO=0.  conv6 (64 -> 64 on 7,680 voxels) stays direct: with two-plane tiles it has

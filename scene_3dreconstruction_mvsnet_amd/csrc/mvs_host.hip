@@ -116,11 +116,9 @@ int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_pa
                 }
         }
     }
-    pack_conv0_pair_weights(blob + L.w_off[0], blob + L.c0p_off);
     pack_conv0_4x4_weights(blob + L.w_off[0], blob + L.c0q_off);
     pack_conv0_winograd_weights(blob + L.w_off[0], blob + L.c0w_off);
     pack_conv0_wino43_weights(blob + L.w_off[0], blob + L.c0w43_off);
-    pack_conv0_wino44_weights(blob + L.w_off[0], blob + L.c0w44_off);
     for (int l = 2; l <= 4; l += 2)
         pack_convwz_weights(blob + L.w_off[l], kLayers[l].cin, kLayers[l].cout, blob + L.wz_off[l]);
     for (int l = 1; l <= 6; ++l)
@@ -174,8 +172,7 @@ int mvs_warp_variance(const float* feats, const float* rt, const float* depth_va
                               dtype, stream);
 }
 
-// CostRegNet from the variance volume, or -- var == NULL -- from an already computed conv0
-// output sitting in the workspace's act[0] region (fused warp+variance+conv0 path).
+// CostRegNet from the variance volume (models/mvsnet.py:64-73)
 static int costreg_impl(const void* var, const void* weights_blob, float* cost_out, void* workspace,
                         size_t workspace_bytes, int D, int h, int w, int dtype, void* stream) {
     if (!weights_blob || !cost_out || !workspace)
@@ -198,7 +195,7 @@ static int costreg_impl(const void* var, const void* weights_blob, float* cost_o
     };
     // models/mvsnet.py:64-73
     int st;
-    if (var && (st = run(0, var, nullptr, act(0)))) return st;  // conv0 (skipped when act(0) is given)
+    if ((st = run(0, var, nullptr, act(0)))) return st;         // conv0
     if ((st = run(1, act(0), nullptr, act(1)))) return st;     // conv1 (s2)
     if ((st = run(2, act(1), nullptr, act(2)))) return st;     // conv2
     if ((st = run(3, act(2), nullptr, act(3)))) return st;     // conv3 (s2)
@@ -218,26 +215,6 @@ int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_o
                         void* stream) {
     if (!var) return fail(MVS_ERR_NULL, "mvs_costreg_forward: NULL argument");
     return costreg_impl(var, weights_blob, cost_out, workspace, workspace_bytes, D, h, w, dtype, stream);
-}
-
-int mvs_warp_conv0(const float* feats, const float* rt, const float* depth_values,
-                   const void* weights_blob, void* conv0_out, void* workspace, size_t workspace_bytes,
-                   int N, int C, int D, int h, int w, int dtype, void* stream) {
-    if (!feats || !depth_values || !weights_blob || !conv0_out || !workspace || (N > 1 && !rt))
-        return fail(MVS_ERR_NULL, "mvs_warp_conv0: NULL argument");
-    if (int st = check_dims(N, C, D, h, w, dtype)) return st;
-    const Workspace W = workspace_layout(N, C, D, h, w, dtype);
-    if (workspace_bytes < W.rt)
-        return fail(MVS_ERR_WORKSPACE, "workspace needs >= %zu bytes, got %zu", W.rt, workspace_bytes);
-    if (reinterpret_cast<uintptr_t>(workspace) & 255)
-        return fail(MVS_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    float* feats_t = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.feats_t);
-    if (int st = launch_nchw_to_c8(feats, feats_t, N, C, h, w, MVS_F32, s)) return st;
-    const BlobLayout L = blob_layout();
-    const float* blob = static_cast<const float*>(weights_blob);
-    return launch_warp_conv0_fused(feats_t, rt, depth_values, blob + L.c0p_off, blob + L.b_off[0],
-                                   conv0_out, N, D, h, w, dtype, s);
 }
 
 int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
@@ -293,32 +270,19 @@ static int depth_infer_impl(const float* feats, const float* proj, const float* 
     int st;
     // from NCHW features the relative projections ride along with the layout transpose (one launch
     // less); with the features already C8-planar in the workspace they get their own 1-block launch
-    static const bool no_fuse = [] {
-        const char* e = getenv("MVS_FUSE");
-        return !(e && e[0] == '1');
-    }();
-    const bool fold_proj = no_fuse && feats != nullptr && N > 1 && N <= 256;
+    const bool fold_proj = feats != nullptr && N > 1 && N <= 256;
     if (!fold_proj && (st = mvs_relative_proj(proj, rt, N, stream))) return st;
     // CostRegNet activations live behind the variance volume; hand costreg the sub-workspace that
     // starts at act[0] laid out as for N = 1 (same relative offsets).
     const Workspace W1 = workspace_layout(1, C, D, h, w, dtype);
     char* sub = ws + (W.act[0] - W1.act[0]);
     const size_t sub_bytes = workspace_bytes - (size_t)(sub - ws);
-    // Default: materialise the variance volume and run conv0 as its own kernel -- on MI355X the two
-    // separate kernels (0.29 + 0.57 ms at cfg2) beat the fused kernel (1.40 ms: one block per CU
-    // cannot keep enough gathers in flight).  MVS_FUSE=1 selects the fused path.
-    if (no_fuse || !feats) {
-        if ((st = warp_variance_impl(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D,
-                                     h, w, dtype, stream, fold_proj ? proj : nullptr)))
-            return st;
-        if ((st = costreg_impl(var, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream))) return st;
-    } else {
-        if ((st = mvs_warp_conv0(feats, rt, depth_values, weights_blob, ws + W.act[0], workspace,
-                                 workspace_bytes, N, C, D, h, w, dtype, stream)))
-            return st;
-        if ((st = costreg_impl(nullptr, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream)))
-            return st;
-    }
+    // The variance volume is materialised and conv0 runs as its own kernel: a fused producer/consumer
+    // kernel measured 1.40 ms against 0.16 + 0.34 ms at cfg2 (csrc/attic/warp_conv0_fused.hip).
+    if ((st = warp_variance_impl(feats, rt, depth_values, var, workspace, workspace_bytes, N, C, D, h, w, dtype,
+                                 stream, fold_proj ? proj : nullptr)))
+        return st;
+    if ((st = costreg_impl(var, weights_blob, cost, sub, sub_bytes, D, h, w, dtype, stream))) return st;
     return mvs_softargmin_conf(cost, depth_values, depth_out, conf_out, D, h, w, stream);
 }
 

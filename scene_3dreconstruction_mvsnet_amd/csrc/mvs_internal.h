@@ -39,14 +39,12 @@ constexpr LayerSpec kLayers[MVS_NUM_LAYERS] = {
 struct BlobLayout {
     size_t w_off[MVS_NUM_LAYERS];  // in floats
     size_t b_off[MVS_NUM_LAYERS];  // in floats
-    size_t c0p_off;                // conv0 Toeplitz "pair" panel [4][18][64][4] (conv3d_mfma.hip)
     size_t c0q_off;                // conv0 4x4x1 panel [4][27][2][2][4][4] (conv3d_mfma.hip)
     size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 and deconv panels of 7..9
     size_t h16_off[2][10];         // 16-bit MFMA panels of layers 0..9 for MVS_F16 ([0]) / MVS_BF16 ([1])
     size_t c0w_off;                // conv0 Winograd-z panel [4][4][9][2][2][4][4] (conv0_winograd.hip)
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv0_winograd.hip)
     size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv0_wino43.hip)
-    size_t c0w44_off;              // conv0 Winograd F(4,3)-z,y panel [4][6][6][3][2][2][4][4] (conv0_wino44.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -60,8 +58,6 @@ inline BlobLayout blob_layout() {
         off += (size_t)kLayers[l].cout;
         off = (off + 63) & ~(size_t)63;
     }
-    L.c0p_off = off;
-    off += (size_t)4 * 18 * 64 * 4;
     L.c0q_off = off;
     off += (size_t)4 * 27 * 2 * 2 * 4 * 4;
     for (int l = 1; l <= 6; ++l) {
@@ -88,8 +84,6 @@ inline BlobLayout blob_layout() {
     }
     L.c0w43_off = off;
     off += (size_t)4 * 6 * 9 * 2 * 2 * 4 * 4;
-    L.c0w44_off = off;
-    off += (size_t)4 * 6 * 6 * 3 * 2 * 2 * 4 * 4;
     L.total_floats = off;
     return L;
 }
@@ -214,15 +208,11 @@ int launch_warp_variance16(const void* feats16, const float* rt, const float* dv
 int launch_relative_proj(const float* proj, float* rt, int N, hipStream_t s);
 int launch_warp_variance(const float* feats_t, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s);
+bool warp_tc_fits(int N, int D, int h, int w, int fes, int ves);   // the tap-cache kernel's range
 int launch_warp_variance_tc(const float* feats_p, const float* rt, const float* dv, void* var, int N, int D,
                             int h, int w, int dtype, hipStream_t s);
 int launch_warp_variance_tc16(const void* feats16, const float* rt, const float* dv, void* var, int N, int D,
                               int h, int w, int dtype, hipStream_t s);
-int launch_warp_variance_lds(const float* feats_p, const float* rt, const float* dv, void* var, int N,
-                             int D, int h, int w, hipStream_t s);
-int launch_warp_conv0_fused(const float* feats_p, const float* rt, const float* dv, const float* bp,
-                            const float* bias, void* y, int N, int D, int h, int w, int dtype,
-                            hipStream_t s);
 int launch_homo_warp(const float* fea, const float* rt, const float* dv, float* out, int C, int D,
                      int h, int w, hipStream_t s);
 int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const float* blob,
@@ -235,15 +225,11 @@ void pack_conv0_winograd_weights(const float* wfold, float* bw);
 int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                         int dtype, hipStream_t s);
 void pack_conv0_wino43_weights(const float* wfold, float* bw);
-int launch_conv0_wino44(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
-                        int dtype, hipStream_t s);
-void pack_conv0_wino44_weights(const float* wfold, float* bw);
 int launch_convwz_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int D, int H,
                        int W, int dtype, hipStream_t s);
 void pack_convwz_weights(const float* wfold, int cin, int cout, float* bp);
-int launch_conv0_mfma(const void* x, void* y, const float* bp, const float* bq, const float* bias,
-                      int D, int H, int W, int dtype, hipStream_t s);
-void pack_conv0_pair_weights(const float* wfold, float* bp);
+int launch_conv0_mfma(const void* x, void* y, const float* bq, const float* bias, int D, int H, int W,
+                      int dtype, hipStream_t s);
 void pack_conv0_4x4_weights(const float* wfold, float* bq);
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
                       int Hi, int Wi, int dtype, hipStream_t s);

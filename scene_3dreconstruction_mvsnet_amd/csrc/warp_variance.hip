@@ -313,7 +313,7 @@ int launch_warp_variance16(const void* feats16, const float* rt, const float* dv
         const char* e = getenv("MVS_WARP_TC16");
         return !(e && e[0] == '0');
     }();
-    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 8 < ((size_t)1 << 31))
+    if (use_tc && warp_tc_fits(N, D, h, w, 2, 2))
         return launch_warp_variance_tc16(feats16, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
@@ -334,19 +334,13 @@ int launch_warp_variance16(const void* feats16, const float* rt, const float* dv
 int launch_warp_variance(const float* feats_p, const float* rt, const float* dv, void* var, int N,
                          int D, int h, int w, int dtype, hipStream_t s) {
     if (h < 2 || w < 2) return fail(MVS_ERR_BAD_SHAPE, "warp_variance: h,w must be >= 2");
-    // MVS_WARP_LDS=1 selects the LDS-staged kernel (warp_variance_lds.hip); the L1-gather kernel
-    // below is the default: it is the faster of the two on MI355X so far.
-    static const bool use_lds = [] {
-        const char* e = getenv("MVS_WARP_LDS");
-        return e && e[0] == '1';
-    }();
-    if (use_lds && N <= 64 && dtype == MVS_F32) return launch_warp_variance_lds(feats_p, rt, dv, var, N, D, h, w, s);
     // Tap-cache kernel (warp_variance_tc.hip) for 2..5 views; MVS_WARP_TC=0 keeps the plain gather
     static const bool use_tc = [] {
         const char* e = getenv("MVS_WARP_TC");
         return !(e && e[0] == '0');
     }();
-    if (use_tc && N >= 2 && N <= 5 && (size_t)4 * N * h * w * 8 < ((size_t)1 << 31)) return launch_warp_variance_tc(feats_p, rt, dv, var, N, D, h, w, dtype, s);
+    if (use_tc && warp_tc_fits(N, D, h, w, 4, dtype == MVS_F32 ? 4 : 2))
+        return launch_warp_variance_tc(feats_p, rt, dv, var, N, D, h, w, dtype, s);
     const unsigned nd = (D + kWarpDepthSlab - 1) / kWarpDepthSlab;
     const unsigned np = (h * w + kWarpPixPerBlock - 1) / kWarpPixPerBlock;
     float* v = static_cast<float*>(var);

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l1
+from conftest import assert_conf_close, load_fixture, rel_l1
 from oracle import oracle as orc
 from scene_3dreconstruction_mvsnet_amd import _lib, synthetic
 
@@ -104,6 +104,67 @@ def test_cfg2_cost_volume_and_maps_match_oracle(cfg2):
     r = rel_l1(depth.cpu().numpy(), o["depth"])
     assert r < 5e-6, r                                    # north_star bound: 1e-3
     assert (np.abs(conf.cpu().numpy() - o["conf"]) > 5e-3).mean() < 0.01
+
+
+def test_cfg2_maps_match_the_reference_fixture(cfg2):
+    """bench.py's workload against maps produced by the imported REFERENCE itself (tests/golden/fx_cfg2_maps.npz,
+    made by tests/golden/gen_golden_cfg2.py with the reference's homo_warping / CostRegNet / depth_regression):
+    the number bench.py times is pinned to the reference directly, not only through the oracle."""
+    fx = load_fixture("cfg2_maps")
+    N, _, h, w = cfg2["feats"].shape
+    D = cfg2["dv"].shape[0]
+    assert abs(float(np.abs(cfg2["feats"].astype(np.float64)).sum()) / float(fx["feats_checksum"]) - 1) < 1e-6
+    ws = _lib.alloc_workspace(N, 32, D, h, w, DEV)
+    depth = torch.empty((h, w), dtype=torch.float32, device=DEV)
+    conf = torch.empty_like(depth)
+    _lib.depth_infer(cu(cfg2["feats"]), cu(cfg2["proj"]), cu(cfg2["dv"]), cfg2["blob"], ws, depth, conf)
+    r = rel_l1(depth.cpu().numpy(), fx["depth"])
+    print(f"[cfg2] depth rel-L1 vs the reference fixture = {r:.3e}")
+    assert r < 5e-6, r                                    # north_star bound: 1e-3
+    assert_conf_close(conf.cpu().numpy(), fx["photometric_confidence"], fx["expected_index"], atol=5e-4)
+
+
+def test_cfg2_fused_conv11_prob_matches_oracle(cfg2):
+    """mvs_conv11_prob (conv11 + conv0 skip + prob in ONE kernel, the default tail of the fp32 path) on its own
+    at the bench size: fed with the oracle's d9 and c0, compared with the oracle's logits
+    (models/mvsnet.py:71-72).  The kernel leans on one wave's LDS operations executing in order."""
+    o = cfg2["o"]
+    cost = _lib.conv11_prob(_lib.to_c8(cu(o["d9"])), _lib.to_c8(cu(o["c0"])), cfg2["blob"]).cpu().numpy()
+    want = o["cost"]
+    assert cost.shape == want.shape
+    np.testing.assert_allclose(cost, want, rtol=0, atol=LAYER_ATOL * max(float(np.abs(want).max()), 1.0))
+    assert rel_l1(cost, want) < 2e-6, rel_l1(cost, want)
+    again = _lib.conv11_prob(_lib.to_c8(cu(o["d9"])), _lib.to_c8(cu(o["c0"])), cfg2["blob"]).cpu().numpy()
+    assert np.array_equal(cost, again)                    # no race: bit-identical from run to run
+
+
+@pytest.mark.parametrize("layer,shape", [(0, (32, 48, 64, 96)), (2, (16, 32, 48, 64)), (4, (32, 16, 24, 32))])
+def test_winograd_layers_on_a_heavy_tailed_nonnegative_volume(cfg2, layer, shape):
+    """conv0 (Winograd F(4,3) along z: constants 4, 5, 8, 1/6, 1/24) and conv2 / conv4 (F(2,3)) on an input shaped
+    like a variance volume of trained features -- non-negative, heavy-tailed (exp(3 N(0,1)): dynamic range
+    > 1e4) -- where the transforms' cancellation error is relative to the LARGEST neighbour, not to the voxel.
+    Bound: |err| <= 2.5e-7 (4 ulp) x the maximum of |input| over the 9x3x3 neighbourhood that can reach the output
+    through the transform x the layer's weight mass (sum |w| per output channel); measured: conv0 4e-8, conv2 1.6e-8,
+    conv4 1.2e-8 of that scale (rel-L1 9e-7 / 4e-7 / 5e-7) -- F(4,3) along z costs no accuracy on such data."""
+    sd = cfg2["sd"]
+    C, D, h, w = shape
+    g = np.random.default_rng(77 + layer)
+    x = np.exp(3.0 * g.standard_normal((C, D, h, w))).astype(np.float32)
+    assert x.max() / np.median(x) > 1e4
+    name = f"conv{layer}"
+    want = orc.conv3d(x, sd[f"{name}.conv.weight"], bn=orc._bn(sd, f"{name}.bn"))
+    got = _lib.from_c8(_lib.conv_layer(layer, _lib.to_c8(cu(x)), None, cfg2["blob"])).cpu().numpy()
+    # local scale: max |x| over the channel axis and a +-4 (z: an F(4,3) tile reads 6 planes for 4 outputs) x +-1 x +-1 window
+    m = torch.from_numpy(x.max(axis=0))[None, None]
+    m = torch.nn.functional.max_pool3d(m, kernel_size=(9, 3, 3), stride=1, padding=(4, 1, 1))[0, 0].numpy()
+    gamma, beta, mean, var_ = orc._bn(sd, f"{name}.bn")
+    wmass = (np.abs(sd[f"{name}.conv.weight"]).reshape(want.shape[0], -1).sum(1) * np.abs(gamma) / np.sqrt(var_ + 1e-5))
+    bound = 2.5e-7 * wmass[:, None, None, None] * m[None] + 1e-6
+    err = np.abs(got - want)
+    worst = float((err / bound).max())
+    print(f"[{name} heavy-tailed] max err / bound = {worst:.3f}, rel-L1 = {rel_l1(got, want):.2e}")
+    assert worst <= 1.0, worst
+    assert rel_l1(got, want) < 5e-6
 
 
 def test_cfg2_layer_test_would_catch_a_dropped_tap(cfg2):

@@ -119,47 +119,13 @@ def test_depth_regression_matches_reference():
 
 @pytest.mark.parametrize("D,h,w", [(8, 8, 8), (8, 16, 40), (16, 24, 72), (10, 8, 96)])
 def test_conv0_mfma_matches_oracle(D, h, w):
-    """The fp32-MFMA conv0 kernel (Toeplitz pair panel, ragged x tiles) against the oracle."""
+    """The default fp32-MFMA conv0 kernel (Winograd F(4,3) along z, ragged x tiles) against the oracle."""
     rng = np.random.default_rng(5)
     x = rng.standard_normal((32, D, h, w)).astype(np.float32)
     sd = synthetic.random_costreg_state(seed=9)
     want = orc.conv3d(x, sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
     got = _lib.from_c8(_lib.conv_layer(0, _lib.to_c8(cu(x)), None, blob_for(sd))).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1.0))
-
-
-@pytest.mark.parametrize("name", ["tiny", "small", "n5yaw", "oob"])
-def test_fused_warp_conv0_matches_reference(name):
-    """mvs_warp_conv0 (variance never materialised) vs conv0 applied to the reference's variance."""
-    fx = load_fixture(name)
-    sd = costreg_sd(fx)
-    feats, proj, dv = fx["features"][0], fx["proj_matrices"][0], fx["depth_values"][0]
-    N, C, h, w = feats.shape
-    ws = _lib.alloc_workspace(N, C, dv.shape[0], h, w, DEV)
-    y = _lib.warp_conv0(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), blob_for(sd), ws)
-    want = orc.conv3d(fx["variance"][0], sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
-    got = _lib.from_c8(y).cpu().numpy()
-    np.testing.assert_allclose(got, want, rtol=0, atol=3e-4 * max(np.abs(want).max(), 1.0))
-
-
-@pytest.mark.parametrize("N,h,w,D", [(3, 8, 8, 8), (4, 24, 40, 32), (2, 16, 24, 56), (5, 40, 72, 24)])
-def test_fused_warp_conv0_matches_unfused(N, h, w, D):
-    """Ragged tiles, several depth segments (D > 24) and view counts: fused == unfused kernels."""
-    feats = synthetic.random_features(N, 32, h, w, seed=7)
-    proj = synthetic.cameras(N, h, w, yaw_deg=1.0)
-    dv = synthetic.depth_values(D)
-    sd = synthetic.random_costreg_state(seed=8)
-    blob = blob_for(sd)
-    ws = _lib.alloc_workspace(N, 32, D, h, w, DEV)
-    rt = _lib.relative_proj(cu(proj))
-    fused = _lib.warp_conv0(cu(feats), rt, cu(dv), blob, ws)
-    unfused = _lib.conv_layer(0, _lib.warp_variance(cu(feats), rt, cu(dv), ws), None, blob)
-    torch.cuda.synchronize()
-    a, b = fused.cpu().numpy(), unfused.cpu().numpy()
-    np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * max(np.abs(b).max(), 1.0))
-    want = orc.conv3d(orc.variance_volume(feats, proj, dv), sd["conv0.conv.weight"], bn=orc._bn(sd, "conv0.bn"))
-    np.testing.assert_allclose(_lib.from_c8(fused).cpu().numpy(), want, rtol=0,
-                               atol=3e-4 * max(np.abs(want).max(), 1.0))
 
 
 @pytest.mark.parametrize("D,h,w", [(8, 8, 8), (8, 16, 24), (16, 32, 40), (24, 40, 72), (40, 56, 64), (16, 128, 8)])
@@ -299,24 +265,11 @@ def test_nonfinite_coordinates_give_nan_like_torch():
 
 
 @pytest.mark.parametrize("env", [
-    {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off)
-    {"MVS_WARP_TC": "1"},        # first form of the tap-cache kernel (three re-gather paths, 8 channels per thread)
-    {"MVS_WARP_CPT": "8"},       # second form with 8 channels per thread
-    {"MVS_WARP_PAIR": "0"},      # second form, every quad evaluating every depth's projections
-    {"MVS_WARP_NT": "1"},        # non-temporal volume stores
+    {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off; also the N > 5 path)
     {"MVS_CONV0_WINO": "2"},     # conv0 with Winograd F(2,3) along z instead of F(4,3)
-    {"MVS_CONV0_WINO": "6"},     # conv0 with Winograd F(4,3) along z and y
-    {"MVS_WARP_LDS": "1"},       # LDS-staged warp+variance kernel
     {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
-    {"MVS_CONV0_PAIR": "1"},     # conv0 on 16x16x4 MFMA with the Toeplitz pair panel
-    {"MVS_CONV0_8W": "1"},       # 8-wave split-K conv0
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
-    {"MVS_FUSE": "1"},           # fused warp+variance+conv0 kernel inside mvs_depth_infer
-    {"MVS_PROB_GATHER": "1", "MVS_FUSE_PROB": "0"},   # prob conv with global gathers instead of the LDS tile
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
-    {"MVS_FUSE_PROB_FORM": "1"}, # fused conv11+prob with the shared input halo (six barriers per step)
-    {"MVS_FUSE_PROB_NT": "256"}, # ... and four waves per block
-    {"MVS_FUSE_PROB_ZC": "4"},   # ... with short z chunks (many chunk seams)
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each

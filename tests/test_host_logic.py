@@ -77,20 +77,6 @@ def test_pack_weights_folds_bn_and_relayouts():
         off = (off + 27 * ci * co + 63) // 64 * 64
         np.testing.assert_allclose(blob[off:off + co], shift, rtol=2e-6, atol=1e-7)
         off = (off + co + 63) // 64 * 64
-    # conv0 "pair" panel for the MFMA kernel: Toeplitz-expanded [4 chunks][18 k-steps][64][4]
-    panel = blob[off:off + 4 * 18 * 64 * 4].reshape(4, 18, 64, 4)
-    w0 = blob[:27 * 32 * 8].reshape(3, 3, 3, 32, 8)  # folded conv0 weights [kz][ky][kx][ci][co]
-    for c, ks, lane in [(0, 0, 0), (1, 5, 17), (2, 9, 40), (3, 17, 63), (0, 3, 57), (2, 12, 9)]:
-        g, n = lane >> 4, lane & 15
-        tap = 2 * ks + (g >> 1)
-        kz, ky, kxp = tap // 12, (tap // 4) % 3, tap % 4
-        j, co = n >> 3, n & 7
-        for j4 in range(4):
-            ci = 8 * c + 4 * (g & 1) + j4
-            kx = kxp - j
-            want = w0[kz, ky, kx, ci, co] if 0 <= kx <= 2 else 0.0
-            assert panel[c, ks, lane, j4] == want
-    off += 4 * 18 * 64 * 4
     # conv0 4x4x1 panel [4 chunks][27 taps][2 halves][2 nt][4 j][4 k]
     q = blob[off:off + 4 * 27 * 2 * 2 * 4 * 4].reshape(4, 27, 2, 2, 4, 4)
     w0t = blob[:27 * 32 * 8].reshape(27, 32, 8)
@@ -173,16 +159,6 @@ def test_pack_weights_folds_bn_and_relayouts():
         np.testing.assert_allclose(w43[c, t, tap, half, nt, j, k], G43[t][tap, 8 * c + 4 * half + k, 4 * nt + j],
                                    rtol=1e-6, atol=1e-9)
     off += 4 * 6 * 9 * 2 * 2 * 4 * 4
-    # conv0 Winograd F(4,3)-z,y panel [4 chunks][6 t][6 v][3 kx][2 halves][2 nt][4 j][4 k] (conv0_wino44.hip)
-    w44 = blob[off:off + 4 * 6 * 6 * 3 * 2 * 2 * 4 * 4].reshape(4, 6, 6, 3, 2, 2, 4, 4)
-    Gm = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
-                   [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
-    g5 = blob[:27 * 32 * 8].reshape(3, 3, 3, 32, 8).astype(np.float64)   # [kz][ky][kx][ci][co]
-    for c, t, v, kx, half, nt, j, k in [(0, 0, 0, 0, 0, 0, 0, 0), (3, 5, 5, 2, 1, 1, 3, 3), (1, 1, 4, 1, 0, 1, 2, 1),
-                                        (2, 3, 2, 0, 1, 0, 1, 3), (0, 4, 1, 2, 0, 0, 3, 2), (3, 2, 3, 1, 1, 1, 0, 0)]:
-        want = np.einsum("a,b,ab->", Gm[t], Gm[v], g5[:, :, kx, 8 * c + 4 * half + k, 4 * nt + j])
-        np.testing.assert_allclose(w44[c, t, v, kx, half, nt, j, k], want, rtol=1e-6, atol=1e-9)
-    off += 4 * 6 * 6 * 3 * 2 * 2 * 4 * 4
     assert off * 4 == _lib.query_weights_blob()
 
 

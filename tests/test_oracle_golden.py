@@ -93,3 +93,25 @@ def test_feature_net_matches_reference_features(name, weights):
         for v in range(imgs.shape[1]):
             got = orc.feature_net(imgs[b, v], weights)
             np.testing.assert_allclose(got, feats[b, v], rtol=1e-4, atol=2e-5)
+
+
+def cfg2_workload():
+    """bench.py's timed problem (seed 0), regenerated from the recipe."""
+    from scene_3dreconstruction_mvsnet_amd import synthetic
+    c = synthetic.CONFIGS["cfg2"]
+    N, h, w, D = c["nviews"], c["H"] // 4, c["W"] // 4, c["D"]
+    return (synthetic.random_features(N, 32, h, w, seed=0), synthetic.cameras(N, h, w),
+            synthetic.depth_values(D, interval_scale=c["interval_scale"]), synthetic.random_costreg_state(seed=0))
+
+
+def test_oracle_matches_reference_at_the_bench_size():
+    """The oracle on bench.py's full cfg2 workload against the maps the imported reference produced for it
+    (tests/golden/gen_golden_cfg2.py: homo_warping + CostRegNet + softmax / depth_regression / confidence of
+    /root/reference on CPU) -- the bench workload itself is pinned to the reference, not only small shapes."""
+    fx = load_fixture("cfg2_maps")
+    feats, proj, dv, sd = cfg2_workload()
+    assert abs(float(np.abs(feats.astype(np.float64)).sum()) - float(fx["feats_checksum"])) < 1e-6 * float(fx["feats_checksum"])
+    depth, conf = orc.depth_infer(feats, proj, dv, sd)
+    r = rel_l1(depth, fx["depth"])
+    assert r < 2e-6, r                       # measured 2.3e-7; north_star bound 1e-3
+    assert_conf_close(conf, fx["photometric_confidence"], fx["expected_index"], atol=5e-4)
