@@ -472,6 +472,12 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         }();
         if (wz) return launch_convwz_mfma(layer, x, y, blob + L.wz_off[layer], blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     }
+    // the 1/8-resolution layers conv5 / conv6 / conv7: all-K-resident split-K kernels (conv3d_small.hip)
+    if (convs_covers(layer)) {
+        if (kLayers[layer].kind == kConv)
+            return launch_convs_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
+        return launch_deconvs_mfma(layer, x, skip, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
+    }
     if (layer >= 1 && layer <= 6)
         return launch_convg_mfma(layer, x, y, blob + L.gp_off[layer], blob + L.b_off[layer], Di, Hi, Wi,
                                  dtype, s);

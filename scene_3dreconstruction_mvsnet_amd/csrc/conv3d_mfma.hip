@@ -627,13 +627,11 @@ static int launch_convg_dt(int layer, const void* x, void* y, const float* bp, c
         case 2: return run_convg<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 3: return run_convg<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 4: return run_convg<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 5: return run_convg<DT, 32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 6: return run_convg<DT, 64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "convg_mfma: layer %d not covered", layer);
     }
 }
 
-// layers 1..6 (conv1..conv6)
+// layers 1..4 (conv1..conv4; conv5 / conv6: conv3d_small.hip)
 int launch_convg_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
                       int Hi, int Wi, int dtype, hipStream_t s) {
     MVS_DISPATCH_DTYPE(dtype, (launch_convg_dt<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s)))
@@ -901,14 +899,13 @@ template <int DT>
 static int launch_deconvg_dt(int layer, const void* x, const void* skip, void* y, const float* bp,
                              const float* bias, int Di, int Hi, int Wi, hipStream_t s) {
     switch (layer) {
-        case 7: return run_deconvg<DT, 64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         case 8: return run_deconvg<DT, 32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         case 9: return run_deconvg<DT, 16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "deconvg_mfma: layer %d not covered", layer);
     }
 }
 
-// layers 7..9 (conv7, conv9, conv11)
+// layers 8, 9 (conv9, conv11; conv7: conv3d_small.hip)
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s) {
     MVS_DISPATCH_DTYPE(dtype, (launch_deconvg_dt<DT>(layer, x, skip, y, bp, bias, Di, Hi, Wi, s)))

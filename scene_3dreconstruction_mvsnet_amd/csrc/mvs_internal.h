@@ -237,6 +237,12 @@ void pack_convg_weights(const float* wfold, int cin, int cout, float* bp);
 int launch_deconvg_mfma(int layer, const void* x, const void* skip, void* y, const float* bp,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_deconvg_weights(const float* wfold, int cin, int cout, float* bp);
+// all-K-resident split-K kernels for the small levels (conv3d_small.hip); same panels as convg / deconvg
+bool convs_covers(int layer);
+int launch_convs_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int Di, int Hi, int Wi,
+                      int dtype, hipStream_t s);
+int launch_deconvs_mfma(int layer, const void* x, const void* skip, void* y, const float* bp, const float* bias, int Di,
+                        int Hi, int Wi, int dtype, hipStream_t s);
 // conv11 (+ conv0 skip) and prob in one kernel, fp32 storage only (conv11_prob.hip)
 int launch_conv11_prob(const void* x, const void* skip, float* cost, const float* blob, int Di, int Hi,
                        int Wi, int dtype, hipStream_t s);
