@@ -675,3 +675,41 @@ def test_two_ranks_gather_over_rccl_and_bench_self_launch():
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("N,h,w,D,kw", [
+    (5, 32, 40, 48, {}),                                   # cfg1-like rig, bands of out-of-image samples
+    (4, 24, 72, 32, dict(baseline=(-90.0, 25.0, 0.0))),    # most samples of the far views outside (whole waves skip)
+    (3, 16, 24, 16, dict(baseline=(-1e5, 0.0, 0.0))),      # every source sample outside: variance of the reference alone
+    (5, 40, 56, 24, dict(yaw_deg=2.5)),                    # rotated rig: cells change often, ragged last block
+])
+def test_tap_cache_kernel_is_bit_identical_to_the_plain_kernel(tmp_path, N, h, w, D, kw):
+    """warp_variance_tc2 (taps cached across depth, zero-weight views skipped per wave, lean projection) against the
+    plain gather kernel (MVS_WARP_TC=0, read once per process -> child process): same taps, same weights, same fma
+    nesting, so the volumes must be EQUAL, not close."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    feats = synthetic.random_features(N, 32, h, w, seed=11)
+    proj = synthetic.cameras(N, h, w, **kw)
+    dv = synthetic.depth_values(D)
+    np.savez(tmp_path / "in.npz", feats=feats, proj=proj, dv=dv)
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from scene_3dreconstruction_mvsnet_amd import _lib\n"
+        "z = np.load(sys.argv[1]); dev = 'cuda:0'; cu = lambda a: torch.from_numpy(a).to(dev)\n"
+        "N, C, h, w = z['feats'].shape\n"
+        "ws = _lib.alloc_workspace(N, C, z['dv'].shape[0], h, w, dev)\n"
+        "v = _lib.warp_variance(cu(z['feats']), _lib.relative_proj(cu(z['proj'])), cu(z['dv']), ws)\n"
+        "np.save(sys.argv[2], v.cpu().numpy())\n") % os.path.dirname(here)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / "plain.npy")],
+                       env=dict(os.environ, MVS_WARP_TC="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ws = _lib.alloc_workspace(N, 32, D, h, w, DEV)
+    got = _lib.warp_variance(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), ws).cpu().numpy()
+    want = np.load(tmp_path / "plain.npy")
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    ref = orc.variance_volume(feats, proj, dv)
+    np.testing.assert_allclose(_lib.from_c8(torch.from_numpy(got)).numpy(), ref, rtol=0, atol=5e-4)
