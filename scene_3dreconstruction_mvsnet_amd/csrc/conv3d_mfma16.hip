@@ -25,6 +25,7 @@ namespace mvs {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 template <int DT>
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
@@ -363,6 +364,169 @@ __global__ __launch_bounds__(256) void conv0p16_mfma_kernel(
     }
 }
 
+// =============================================================================================
+// conv0z16: conv0 (32 -> 8) for 16-bit storage as a z-MARCHING kernel (default; conv0p16 above is the small-shape
+// form).  In the 16-bit modes conv0 is not matrix-bound (the 16-bit MFMA is 16x the fp32 rate) but bound by the
+// bytes it moves: conv0p16 re-stages a 4 x 10 x 34 halo per 2 x 8 x 32 outputs (2.66x the input through L2 ->
+// LDS, 8 block barriers per tile, 2-byte scattered stores) and ran at 29 % of HBM at cfg3 (1.05 ms; this kernel:
+// 0.58 ms = 52 %; cfg5 0.131 -> 0.077 ms).  Here a block owns an
+// 8 x 32 (y, x) column of the volume and marches along z:
+//   * a ring of four input planes (all 32 channels, 10 x 34 halo) lives in LDS; every input plane is fetched
+//     ONCE per column (halo only in y / x: 1.33x), requested three steps ahead into registers and written into the
+//     slot of the plane that has just left the stencil -- one barrier per output plane;
+//   * 512 threads: wave w owns output row w; the whole 36-k-step Toeplitz panel (4 chunks x 9 (kz, ky) steps,
+//     144 VGPRs) stays in registers, a step is 36 ds_read_b128 + 36 MFMAs per wave;
+//   * epilogue: ReLU(acc + bias) is packed to 16 bit, transposed through a wave-private LDS strip (one wave's
+//     LDS operations execute in order) and leaves as 16-byte stores, one voxel per lane.
+// Same panel and same k order as conv0p16 (chunk-major, then kz, ky): identical results.
+// =============================================================================================
+namespace c0z {
+constexpr int TY = 8, TX = 32, HY = TY + 2, HX = TX + 2;
+constexpr int CH = HY * HX * 8;                  // 16-bit elements of one chunk of one plane
+constexpr int SLOT = 4 * CH;                     // one plane: [chunk][hy][hx][8]
+constexpr int RING = 4;
+constexpr int THREADS = 64 * TY;                 // 512
+constexpr int NPIECE = 4 * HY * HX;              // 16-byte pieces of one plane (1360)
+constexpr int PPT = (NPIECE + THREADS - 1) / THREADS;   // 3
+constexpr int OUTW = TX * 8;                     // 16-bit elements of one output row
+}  // namespace c0z
+
+template <int DT>
+__global__ __launch_bounds__(c0z::THREADS) void conv0z16_mfma_kernel(
+    const void* __restrict__ x,             // [4][D][H][W][8] 16-bit
+    const unsigned short* __restrict__ bp,  // [4 chunks][9][64][8] 16-bit Toeplitz panel
+    const float* __restrict__ bias,         // [8]
+    void* __restrict__ y,                   // [D][H][W][8] 16-bit
+    int D, int H, int W, int ZC, int nbx, int nby) {
+    using namespace c0z;
+    __shared__ __attribute__((aligned(16))) unsigned short ring[RING * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short outt[TY * OUTW];
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD: speed only, never correctness)
+    // and every XCD has its own L2: XCD k works through the k-th eighth of the (z chunk, row, column) sequence, so
+    // that columns sharing a y / x halo run on the same L2 at about the same time
+    int b;
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;   // XCD k runs q (+1 if k < rem) blocks
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int x0 = bx * TX, y0 = by * TY;
+    const int za = bz * ZC, zb = min(za + ZC, D);
+    const size_t HW8 = (size_t)H * W * 8, V8 = (size_t)D * HW8;
+
+    // staging: piece p = tid + i * THREADS -> (chunk, hy, hx)
+    size_t goff[PPT];
+    int loff[PPT];
+    unsigned okxy = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * THREADS;
+        const int hx = p % HX, t = p / HX;
+        const int hy = t % HY, c = t / HY;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < NPIECE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? (size_t)c * V8 + ((size_t)gy * W + gx) * 8 : 0;
+        okxy |= ok ? (1u << i) : 0u;
+        loff[i] = p < NPIECE ? p * 8 : -1;
+    }
+    auto load_plane = [&](int gz, u32x4 (&st)[PPT]) {   // raw loads (plane clamped into the volume); masked when stored
+        const size_t zo = (size_t)min(max(gz, 0), D - 1) * HW8;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) st[i] = *reinterpret_cast<const u32x4*>(xs + goff[i] + zo);
+    };
+    auto store_plane = [&](int gz, const u32x4 (&st)[PPT]) {   // plane gz -> slot (gz + 1) & 3, zeros outside the volume
+        unsigned short* slot = ring + ((gz + 1) & (RING - 1)) * SLOT;
+        const bool zok = gz >= 0 && gz < D;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (loff[i] >= 0)
+                *reinterpret_cast<u32x4*>(slot + loff[i]) = (zok && ((okxy >> i) & 1u)) ? st[i] : (u32x4){0u, 0u, 0u, 0u};
+    };
+
+    // the whole panel in registers: breg[c][kz * 3 + ky]
+    u32x4 breg[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) breg[c][ks] = reinterpret_cast<const u32x4*>(bp)[(c * 9 + ks) * 64 + lane];
+
+    // prologue: planes za-1, za, za+1 into the ring; planes za+2 and za+3 in flight
+    u32x4 sa[PPT], sb[PPT], sc[PPT];
+    load_plane(za - 1, sa);
+    load_plane(za, sb);
+    load_plane(za + 1, sc);
+    store_plane(za - 1, sa);
+    store_plane(za, sb);
+    store_plane(za + 1, sc);
+    load_plane(za + 2, sa);   // `sa` holds the plane that step za writes, `sb` the one step za + 1 writes
+    load_plane(za + 3, sb);
+    __syncthreads();
+
+    // lane (r = pair index, g = kx' in 0..3): halo x = 2r + g; wave = output row
+    const int r = lane & 15, g = lane >> 4;
+    const int aoff = (wave * HX + 2 * r + g) * 8;
+    const int n = lane & 15, jj = n >> 3, co = n & 7;
+    const float bv = bias[co];
+    unsigned short* orow = outt + wave * OUTW;
+    const int gy = y0 + wave;
+    // epilogue store role: lanes 0..31 own voxel x0 + lane of the wave's row
+    const bool st_ok = lane < TX && gy < H && x0 + lane < W;
+    const unsigned st_off = (unsigned)(((size_t)gy * W + x0 + (lane & 31)) * 16);   // bytes; the launcher checks < 4 GiB
+    const unsigned zstep_b = (unsigned)(HW8 * 2);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, (short)0, (int)(unsigned)(V8 * 2), 0x00020000);
+
+    // one output plane: `nxt` receives plane z + 4 (first read in step z + 3), `cur` holds plane z + 2 (requested two
+    // steps ago) and is written into the ring at the end: three planes (65 KB per CU) are in flight, the three
+    // register sets rotate (the loop is unrolled by three: a register copy would wait for the loads just issued).
+    // The kernel moves 26 KB per step and CU, so what it needs is bytes in flight: at cfg3 two sets (and a branch-free
+    // VMEM stream, below) gave 0.655-0.685 ms, three 0.579, four 0.577
+    auto step = [&](int z, u32x4 (&cur)[PPT], u32x4 (&nxt)[PPT]) {
+        load_plane(z + 4, nxt);   // unconditional (the plane index is clamped): hipcc then keeps counted vmcnt waits
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+            const unsigned short* pl = ring + ((z + kz) & (RING - 1)) * SLOT + aoff;   // plane z - 1 + kz
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(pl + c * CH + ky * HX * 8);
+                    acc = mfma16<DT>(a, breg[c][kz * 3 + ky], acc);
+                }
+        }
+        // epilogue: element e of acc = pair m = 4 g + e -> voxel x = 2 m + jj, channel co
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = fmaxf(acc[e] + bv, 0.0f);
+            unsigned short bits;
+            if (DT == MVS_F16) { const _Float16 hv = (_Float16)v; bits = __builtin_bit_cast(unsigned short, hv); }
+            else { const __bf16 hv = (__bf16)v; bits = __builtin_bit_cast(unsigned short, hv); }
+            orow[(2 * (4 * g + e) + jj) * 8 + co] = bits;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // raw buffer store: lanes without a voxel carry an offset beyond the descriptor's range (dropped by the
+        // hardware) -- an exec-masked store could be branched around, and every branch around a VMEM instruction
+        // makes the compiler fall back to s_waitcnt vmcnt(0), i.e. to waiting for the loads just issued
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const u16x8*>(orow + (lane & 31) * 8)),
+                                               yrs, (int)((st_ok && z < zb) ? st_off + (unsigned)z * zstep_b : 0xFFFFFFF0u), 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        // plane z + 2 replaces plane z - 2, which no step reads any more
+        store_plane(z + 2, cur);   // (a plane beyond zb lands in a slot nobody reads any more)
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int z = za; z < zb; z += 3) {   // up to two surplus steps at the end of a chunk: their stores are dropped
+        step(z, sa, sc);
+        step(z + 1, sb, sa);
+        step(z + 2, sc, sb);
+    }
+}
+
 // wfold [27][32][8] -> bp [4][9][64][8] (16-bit): k = (g = kx', j = ci of the chunk), n = (jj, co)
 void pack_conv0p16_weights(const float* wfold, int dt, unsigned short* bp) {
     for (int c = 0; c < 4; ++c)
@@ -581,6 +745,34 @@ static int launch_layer16_dt(int layer, const void* x, const void* skip, void* y
         using namespace c16;
         if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
             return fail(MVS_ERR_BAD_SHAPE, "conv0p16_mfma: plane exceeds 31-bit offsets");
+        // z-marching kernel once its (y, x) columns can fill the chip; MVS_CONV0Z16=0 keeps the tile kernel (A/B runs)
+        static const int zmarch = [] {   // 1 = also at small shapes (tests), 0 = never
+            const char* e = getenv("MVS_CONV0Z16");
+            return e ? atoi(e) : -1;
+        }();
+        const int ncol = ((Wi + c0z::TX - 1) / c0z::TX) * ((Hi + c0z::TY - 1) / c0z::TY);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        if (zmarch != 0 && Di >= 8 && (size_t)Di * Hi * Wi * 16 < ((size_t)1 << 32) - 64 &&
+            (zmarch == 1 || (size_t)ncol * (Di / 8) >= (size_t)cus / 2)) {
+            // z chunks (>= 8 planes each; every chunk re-reads 2 planes): the split that fills the last round of
+            // one-block-per-CU best
+            int best = 1;
+            double best_eff = 0.0;
+            for (int nz = 1; nz <= Di / 8; ++nz) {
+                const int zc = (Di + nz - 1) / nz, nzc = (Di + zc - 1) / zc;
+                const long nb = (long)ncol * nzc;
+                const double eff = (double)nb / (double)(((nb + cus - 1) / cus) * cus) * zc / (zc + 2.0);
+                if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+            }
+            const int ZC = (Di + best - 1) / best, nzc = (Di + ZC - 1) / ZC;
+            conv0z16_mfma_kernel<DT><<<ncol * nzc, c0z::THREADS, 0, s>>>(x, bp, bias, y, Di, Hi, Wi, ZC,
+                                                                          (Wi + c0z::TX - 1) / c0z::TX,
+                                                                          (Hi + c0z::TY - 1) / c0z::TY);
+            return check_hip(hipGetLastError(), "conv0z16_mfma launch");
+        }
         const int nb = ((Wi + TX - 1) / TX) * ((Hi + TY - 1) / TY) * ((Di + TZ - 1) / TZ);
         conv0p16_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bp, bias, y, Di, Hi, Wi);
         return check_hip(hipGetLastError(), "conv0p16_mfma launch");

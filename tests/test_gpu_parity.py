@@ -320,6 +320,11 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_WARP_DEPTH_FASTEST": "1", "MVS_WARP_TC": "0"}, ("16", "16", "32", "f32")),
     ({"MVS_WARP_DEPTH_FASTEST": "1", "MVS_WARP_TC16": "0"}, ("16", "16", "32", "f16", "bf16")),   # plain 16-bit kernel
     ({"MVS_WARP_TC16": "0"}, ("16", "16", "32", "bf16")),
+    # z-marching 16-bit conv0 (conv3d_mfma16.hip: default once its columns fill the chip): ragged x tile (w = 40),
+    # several z chunks; and the tile kernel it replaces at full size
+    ({"MVS_CONV0Z16": "1"}, ("24", "24", "40", "f16", "bf16")),
+    ({"MVS_CONV0Z16": "1"}, ("16", "16", "32", "bf16")),
+    ({"MVS_CONV0Z16": "0"}, ("16", "16", "32", "f16")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a
