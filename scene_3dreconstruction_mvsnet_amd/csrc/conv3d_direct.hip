@@ -227,6 +227,7 @@ static int run_deconv(const void* x, const void* skip, void* y, const float* wgt
 // halves of a voxel are swapped for odd groups of 8 x positions so that the 32-byte voxel
 // stride stays conflict-free for ds_read_b128.
 // ---------------------------------------------------------------------------------------------
+typedef float f32x2p __attribute__((ext_vector_type(2)));
 namespace pl {
 constexpr int TZ = 4, TY = 8, TX = 32;
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
@@ -325,9 +326,11 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
         const int tn = t + gridDim.x;
         const bool has_next = tn < ntiles;
         if (has_next) load_tile(tn);                  // in flight during the FMAs below
-        float acc[TZ];
+        // (even, odd channel) partial sums: the FMAs are v_pk_fma_f32 with the weights as SGPR pairs -- half the
+        // vector instructions of a scalar fmaf chain (this kernel runs two waves per SIMD and is bound by them)
+        f32x2p acc[TZ];
 #pragma unroll
-        for (int j = 0; j < TZ; ++j) acc[j] = bv;
+        for (int j = 0; j < TZ; ++j) acc[j] = (f32x2p){bv, 0.0f};
 #pragma unroll 1
         for (int kh = 0; kh < MVS_PROB_KH; ++kh)
 #pragma unroll 1
@@ -346,13 +349,14 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
                     // uniform address -> scalar (SMEM) loads, the weights are SGPR operands of the FMAs;
                     // measured 5 % faster than broadcast reads of an LDS copy (one LDS read less per 4 FMAs)
                     const float* wv = wgt + ((kd * 3 + kh) * 3 + kw) * 8;
-                    const float4 w0 = make_float4(wv[0], wv[1], wv[2], wv[3]);
-                    const float4 w1 = make_float4(wv[4], wv[5], wv[6], wv[7]);
+                    const f32x2p w01 = {wv[0], wv[1]}, w23 = {wv[2], wv[3]}, w45 = {wv[4], wv[5]}, w67 = {wv[6], wv[7]};
 #pragma unroll
                     for (int j = 0; j < TZ; ++j) {
                         const int c = j + kd;  // input plane of output j through tap kd
-                        acc[j] = fmaf(a[c].x, w0.x, fmaf(a[c].y, w0.y, fmaf(a[c].z, w0.z, fmaf(a[c].w, w0.w, acc[j]))));
-                        acc[j] = fmaf(bq[c].x, w1.x, fmaf(bq[c].y, w1.y, fmaf(bq[c].z, w1.z, fmaf(bq[c].w, w1.w, acc[j]))));
+                        acc[j] = __builtin_elementwise_fma((f32x2p){a[c].x, a[c].y}, w01, acc[j]);
+                        acc[j] = __builtin_elementwise_fma((f32x2p){a[c].z, a[c].w}, w23, acc[j]);
+                        acc[j] = __builtin_elementwise_fma((f32x2p){bq[c].x, bq[c].y}, w45, acc[j]);
+                        acc[j] = __builtin_elementwise_fma((f32x2p){bq[c].z, bq[c].w}, w67, acc[j]);
                     }
                 }
             }
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void prob_lds_kernel(const void* __restrict
         if (gy < H && gx < W) {
 #pragma unroll
             for (int j = 0; j < TZ; ++j)
-                if (cz0 + j < D) y[((size_t)(cz0 + j) * H + gy) * W + gx] = acc[j];
+                if (cz0 + j < D) y[((size_t)(cz0 + j) * H + gy) * W + gx] = acc[j].x + acc[j].y;
         }
         if (!has_next) break;
         __syncthreads();   // every thread is done reading the current tile
