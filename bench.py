@@ -199,8 +199,9 @@ def main(argv=None):
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
 
-    # the library ends the fp32 path in ONE kernel for conv11 + prob (csrc/conv11_prob.hip) unless MVS_FUSE_PROB=0
-    fused_tail = storage == "f32" and os.environ.get("MVS_FUSE_PROB") != "0"
+    # the library ends the path in ONE kernel for conv11 + prob (csrc/conv11_prob.hip) unless MVS_FUSE_PROB=0 (16-bit
+    # storage: on the 16-bit matrix cores, so not with MVS_MFMA16=0)
+    fused_tail = os.environ.get("MVS_FUSE_PROB") != "0" and (storage == "f32" or os.environ.get("MVS_MFMA16") != "0")
     layer_names = [l[0] for l in LAYERS]
     if fused_tail:
         layer_names = layer_names[:9] + ["conv11_prob"]

@@ -197,20 +197,23 @@ def _fold(sd, wkey, bnprefix, transposed=False):
     return (w * scale[:, None, None, None, None]).astype(np.float32), shift
 
 
-def costreg_forward_arith16(var, sd, storage):
+def costreg_forward_arith16(var, sd, storage, fused_tail=True):
     """CostRegNet with 16-bit MFMA operands (conv3d_mfma16.hip): BN-folded weights rounded to the
-    storage dtype, activations stored in it, fp32 accumulation, fp32 bias/ReLU/skip."""
+    storage dtype, activations stored in it, fp32 accumulation, fp32 bias/ReLU/skip.
+    fused_tail (the HIP path's default since round 3, conv11_prob.hip): conv11's output + skip feeds prob in fp32,
+    it is never stored -- the one tensor of the 16-bit modes that is NOT rounded."""
     q = lambda t: round_storage(t, storage)  # noqa: E731
 
     def conv(x, i, stride=1):
         w, sh = _fold(sd, f"conv{i}.conv.weight", f"conv{i}.bn")
         return q(conv3d(x, q(w), bias=sh, bn=None, stride=stride, relu=True))
 
-    def deconv(x, name, skip):
+    def deconv(x, name, skip, store=True):
         w, sh = _fold(sd, f"{name}.0.weight", f"{name}.1", transposed=True)  # [Cout,Cin,...]
         wt = np.ascontiguousarray(q(w).transpose(1, 0, 2, 3, 4))              # back to [Cin,Cout,...]
         y = deconv3d(x, wt, bn=None, relu=False) + sh[:, None, None, None]
-        return q(skip + np.maximum(y, 0.0))
+        y = skip + np.maximum(y, 0.0)
+        return q(y) if store else y
 
     c0 = conv(var, 0)
     c2 = conv(conv(c0, 1, 2), 2)
@@ -218,7 +221,7 @@ def costreg_forward_arith16(var, sd, storage):
     x = conv(conv(c4, 5, 2), 6)
     x = deconv(x, "conv7", c4)
     x = deconv(x, "conv9", c2)
-    x = deconv(x, "conv11", c0)
+    x = deconv(x, "conv11", c0, store=not fused_tail)
     cost = conv3d(x, sd["prob.weight"], bias=sd["prob.bias"], bn=None, relu=False)
     return cost[0]
 

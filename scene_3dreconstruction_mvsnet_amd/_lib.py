@@ -252,18 +252,19 @@ def conv_layer(layer, x, skip, blob, dtype=MVS_F32):
     return y
 
 
-def conv11_prob(x, skip, blob):
-    """Layers 9 + 10 in one kernel: x [2,Di,Hi,Wi,8], skip [1,2Di,2Hi,2Wi,8] (fp32) -> cost logits [2Di,2Hi,2Wi]."""
+def conv11_prob(x, skip, blob, dtype=MVS_F32):
+    """Layers 9 + 10 in one kernel: x [2,Di,Hi,Wi,8], skip [1,2Di,2Hi,2Wi,8] (storage dtype) -> fp32 cost logits
+    [2Di,2Hi,2Wi]."""
     planes, Di, Hi, Wi, c8 = x.shape
     if planes != 2 or c8 != 8 or tuple(skip.shape) != (1, 2 * Di, 2 * Hi, 2 * Wi, 8):
         raise RuntimeError(f"conv11_prob: shapes {tuple(x.shape)} / {tuple(skip.shape)}")
-    if x.dtype != torch.float32 or skip.dtype != torch.float32:
-        raise RuntimeError("conv11_prob: fp32 storage only")
+    if x.dtype != TORCH_DTYPES[dtype] or skip.dtype != TORCH_DTYPES[dtype]:
+        raise RuntimeError(f"conv11_prob: tensors must be {TORCH_DTYPES[dtype]}")
     if not (x.is_cuda and skip.is_cuda and x.is_contiguous() and skip.is_contiguous()):
         raise RuntimeError("conv11_prob: needs contiguous CUDA(ROCm) tensors")
     cost = torch.empty((2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
     check(load().mvs_conv11_prob(x.data_ptr(), skip.data_ptr(), cost.data_ptr(), blob.data_ptr(), Di, Hi, Wi,
-                                 MVS_F32, _stream(x.device)))
+                                 dtype, _stream(x.device)))
     return cost
 
 

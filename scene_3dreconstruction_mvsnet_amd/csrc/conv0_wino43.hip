@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv0_w43_mfma_kernel(
     float* wlds = tile + TILE_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY, nbz = (D + TZ - 1) / TZ;
+    const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
     // Block -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 names the XCD: speed only,
     // never correctness) and every XCD has its own L2, so halo rows / planes shared by neighbouring
     // tiles are only re-read from L2 when the neighbours run on the SAME XCD, close in time.  Each XCD

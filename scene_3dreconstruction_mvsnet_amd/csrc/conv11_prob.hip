@@ -32,6 +32,8 @@
 // do not overlap on a SIMD.  A producer / consumer split of the waves (MFMA waves feeding stencil waves
 // through a second tile buffer, one barrier per step) measured the same 0.120 ms and was dropped; so were
 // LDS float atomics for the skip add (+0.2 ms).
+#include <cstdlib>
+
 #include "mvs_internal.h"
 #include "storage.h"
 
@@ -48,7 +50,7 @@ constexpr int BY = 4, BX = 2;                      // MFMA M-tiles (2 rows x 8 c
 constexpr int IY = 2 * BY, IX = 8 * BX;            // input tile: 8 x 16 voxels
 constexpr int OY = 2 * IY, OX = 2 * IX;            // conv11 tile: 16 x 32 voxels
 constexpr int PY = OY - 2, PX = OX - 2;            // logits per tile: 14 x 30
-constexpr int HY = IY + 1, HX = IX + 1, HXP = 24;  // input halo (second tap of the odd outputs), x pitch
+
 // conv11 tile in LDS: [plane 2][row OY + 2][half 2][x XP][4 channels], a zero border of one voxel all around;
 // x-adjacent lanes read adjacent 16-byte pieces of one half-row: conflict-free ds_read_b128
 constexpr int XP = 36;
@@ -298,18 +300,257 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
     (void)Do;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same kernel for 16-bit storage (fp16 / bf16 volumes; logits stay fp32): the transposed convolution runs on
+// v_mfma_f32_16x16x32_{f16,bf16} exactly as deconvg16_mfma_kernel (conv3d_mfma16.hip: same panel, 5 k-steps per
+// 8-channel chunk, a lane's A fragment = the 8 channels of one voxel) -- 10 MFMAs per wave and step instead of 72
+// fp32 ones, the panel in registers, both chunks of the wave's 3 x 9 voxel halo staged at once (one 16-byte piece per
+// lane and chunk); skip values arrive as 16-byte pieces of 8 channels.  Scatter, skip add, the z-scatter stencil
+// and its (even, odd) packed sums are the fp32 kernel's.  Replaces deconvg16 (conv11) + prob_lds: the 8-channel
+// full-resolution tensor between them (cfg3: 485 MB written, then read) never reaches HBM.
+// ---------------------------------------------------------------------------------------------
+namespace cpv16 {
+using namespace cp;
+constexpr int RPI = 9 * 8 + 8;               // 16-bit elements per row of a private input tile: 9 voxels x 16 B + 16 B
+constexpr int WIN = 2 * 3 * RPI;             // one chunk: [plane 2][row 3]
+constexpr int NPC = 2 * 27;                  // 16-byte pieces of it: [plane][3 x 9 voxels]
+}  // namespace cpv16
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16v(u32x4v a, u32x4v b, f32x4 c) {
+    if (DT == MVS_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a), __builtin_bit_cast(bf16x8v, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ void unpack8(u32x4v v, float (&o)[8]) {
+    if (DT == MVS_F16) {
+        const f16x8v h = __builtin_bit_cast(f16x8v, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+    } else {
+        const bf16x8v h = __builtin_bit_cast(bf16x8v, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+    }
+}
+template <int DT>
+__global__ __launch_bounds__(512, 4) void conv11_prob16_kernel(
+    const void* __restrict__ x, const unsigned short* __restrict__ bp, const float* __restrict__ bias,
+    const void* __restrict__ skip, const float* __restrict__ pw, const float* __restrict__ pbias,
+    float* __restrict__ cost, int Di, int Hi, int Wi, int ZC, int nbx, int nby) {
+    using namespace cpv16;
+    static_assert(DT == MVS_F16 || DT == MVS_BF16, "16-bit storage");
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+    const unsigned short* sks = static_cast<const unsigned short*>(skip);
+    __shared__ __attribute__((aligned(16))) float ct[C_FLOATS];
+    __shared__ __attribute__((aligned(16))) unsigned short win[8 * 2 * WIN];   // [wave][chunk][plane 2][row 3][RPI]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ix0 = bx * (IX - 1), iy0 = by * (IY - 1);
+    const int za = bz * ZC, zb = min(za + ZC, Di);
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t Vin = (size_t)Di * Hi * Wi, HWi = (size_t)Hi * Wi, HWo = (size_t)Ho * Wo;
+    const int i_first = za > 0 ? za - 1 : 0, i_last = zb < Di ? zb : Di - 1;
+
+    // ---- producer roles (wave-private) ----
+    const int tx = wave & 1, ty = wave >> 1;            // M-tile: input rows 2 ty .. +1, columns 8 tx .. +7
+    unsigned short* my = win + wave * 2 * WIN;
+    // staging: lane -> one 16-byte piece (8 channels of one voxel) of each chunk: [plane hz][row hr][column hc]
+    const int pv = lane < NPC ? lane : NPC - 1;
+    const int phz = pv / 27, pvv = pv % 27, phr = pvv / 9, phc = pvv % 9;
+    const int pgy = iy0 + 2 * ty + phr, pgx = ix0 + 8 * tx + phc;
+    const bool pin = lane < NPC && pgy < Hi && pgx < Wi;
+    const size_t prel = pin ? (((size_t)phz * Hi + pgy) * Wi + pgx) * 8 : 0;
+    const int ploff = (phz * 3 + phr) * RPI + phc * 8;
+    u32x4v pre[2];
+    bool pre_z1 = true;
+    auto load_a = [&](int i) {    // both chunks of input planes i, i + 1; raw loads, masked when they go to LDS
+        pre_z1 = i + 1 < Di;
+        const bool ok = pin && (pre_z1 || phz == 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            pre[c] = *reinterpret_cast<const u32x4v*>(xs + (ok ? ((size_t)c * Vin + (size_t)i * HWi) * 8 + prel : (size_t)0));
+    };
+    auto store_a = [&]() {
+        const bool ok = pin && (pre_z1 || phz == 0);
+        if (lane < NPC) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                *reinterpret_cast<u32x4v*>(my + c * WIN + ploff) = ok ? pre[c] : (u32x4v){0u, 0u, 0u, 0u};
+        }
+    };
+    // MFMA lane roles (deconvg16_mfma_kernel): row r -> input voxel (r >> 3, r & 7) of the M-tile; g: dx = g & 1,
+    // (z, y)-tap combo g >> 1 (deconv16_tap); a lane's A fragment = the 8 channels of one voxel; column n = r -> (px, co)
+    const int r = lane & 15, g = lane >> 4;
+    const int abase = (r >> 3) * RPI + ((r & 7) + (g & 1)) * 8;
+    int koff[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const Deconv16Tap t0 = deconv16_tap(ks, 0), t1 = deconv16_tap(ks, 1);
+        koff[ks] = ((g >> 1) ? (t1.dz * 3 + t1.dy) : (t0.dz * 3 + t0.dy)) * RPI;
+    }
+    const int px = r >> 3, co = r & 7;
+    const float bv = bias[co];
+    // element e of the accumulators: input voxel m = 4 g + e -> tile column 8 tx + (m & 7) = 8 tx + 4 (g & 1) + e
+    const int sbase0 = (2 * (2 * ty + (g >> 1)) + 1) * RS + (co >> 2) * HS + (2 * (8 * tx + 4 * (g & 1)) + px + 1) * 4 + (co & 3);
+    // skip pieces of the wave's strip (8 channels = 16 bytes each): lane -> column xx, row rr; j -> plane
+    const int sxx = lane & 15, srr = lane >> 4;
+    const int soy = 4 * ty + srr, sox = 16 * tx + sxx;
+    const bool sok = 2 * iy0 + soy < Ho && 2 * ix0 + sox < Wo;
+    const size_t srel = sok ? ((size_t)(2 * iy0 + soy) * Wo + 2 * ix0 + sox) * 8 : 0;
+    const int sl = (soy + 1) * RS + (sox + 1) * 4;
+    u32x4v sk[2];
+    auto load_skip = [&](int i, bool de, bool dodd) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = sok && (j ? dodd : de);
+            sk[j] = *reinterpret_cast<const u32x4v*>(sks + (ok ? (size_t)(2 * i + j) * HWo * 8 + srel : (size_t)0));   // masked when added
+        }
+    };
+    // the whole panel (2 chunks x 5 k-steps) in registers
+    u32x4v breg[2][5];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) breg[c][ks] = reinterpret_cast<const u32x4v*>(bp)[(c * 5 + ks) * 64 + lane];
+    f32x4 acc[4];
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int cls = deconv16_tap(ks, 0).cls;
+                const u32x4v a = *reinterpret_cast<const u32x4v*>(my + c * WIN + koff[ks] + abase);
+                acc[cls] = mfma16v<DT>(a, breg[c][ks], acc[cls]);
+            }
+    };
+
+    // ---- stencil roles: thread -> one position of the 16 x 32 tile ----
+    const int lx = tid & 31, ly = tid >> 5;
+    const int gyo = 2 * iy0 + ly, gxo = 2 * ix0 + lx;
+    const bool pvalid = gyo < Ho && gxo < Wo && (ly >= 1 || iy0 == 0) && (ly <= OY - 2 || gyo == Ho - 1) &&
+                        (lx >= 1 || ix0 == 0) && (lx <= OX - 2 || gxo == Wo - 1);
+    const size_t pout = (size_t)gyo * Wo + gxo;
+    const int cbase = ly * RS + lx * 4;   // LDS row r = tile row r - 1, x index lx = tile column lx - 1
+    auto stencil = [&](int plane, f32x2v& k2, f32x2v& k1, f32x2v& k0) {
+        const float* base = ct + plane * PS + cbase;
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {
+            f32x4 v[3][2];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    v[rr][hf] = *reinterpret_cast<const f32x4*>(base + rr * RS + hf * HS + kx * 4);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // uniform addresses: scalar loads, the weights are SGPR-pair operands of v_pk_fma_f32
+                const float* w2 = pw + ((2 * 3 + ky) * 3 + kx) * 8;
+                const float* w1 = pw + ((1 * 3 + ky) * 3 + kx) * 8;
+                const float* w0 = pw + ((0 * 3 + ky) * 3 + kx) * 8;
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    const f32x4 q = v[ky][c2 >> 1];
+                    const f32x2v d = (c2 & 1) ? (f32x2v){q.z, q.w} : (f32x2v){q.x, q.y};
+                    k2 = __builtin_elementwise_fma(d, (f32x2v){w2[2 * c2], w2[2 * c2 + 1]}, k2);
+                    k1 = __builtin_elementwise_fma(d, (f32x2v){w1[2 * c2], w1[2 * c2 + 1]}, k1);
+                    k0 = __builtin_elementwise_fma(d, (f32x2v){w0[2 * c2], w0[2 * c2 + 1]}, k0);
+                }
+            }
+        }
+    };
+    auto emit = [&](int oz, const f32x2v& sv) {
+        if (pvalid) cost[(size_t)oz * HWo + pout] = sv.x + sv.y;
+    };
+
+    const float pb = pbias[0];
+    const f32x2v fresh = {pb, 0.0f};
+    f32x2v A = fresh, B = fresh, C = fresh;
+
+    for (int k = tid; k < C_FLOATS / 4; k += 512) reinterpret_cast<f32x4*>(ct)[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_skip(i_first, i_first >= za, i_first < zb);
+    load_a(i_first);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = i_first; i <= i_last; ++i) {
+        const bool de = i >= za, dodd = i < zb;       // even / odd conv11 plane of this step wanted
+        // ---- wave-private: stage, multiply, scatter, add the skip values ----
+        // (lanes of a wave read what other lanes of the same wave wrote: the LDS executes one wave's
+        // operations in order; wave_barrier() keeps the compiler from reordering across these points)
+        store_a();                                   // both chunks of planes i, i + 1 (requested a step ago)
+        __builtin_amdgcn_wave_barrier();
+        if (i < i_last) load_a(i + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_all();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 2 ? !de : !dodd) continue;
+            float* dst = ct + (c >> 1) * PS + (c & 1) * RS + sbase0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[8 * e] = fmaxf(acc[c][e] + bv, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz) {
+            if (pz ? !dodd : !de) continue;
+            float sv[8];
+            unpack8<DT>(sk[pz], sv);
+            float* d = ct + pz * PS + sl;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(d), t1 = *reinterpret_cast<const f32x4*>(d + HS);
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(d) = sok ? t0 + (f32x4){sv[0], sv[1], sv[2], sv[3]} : z4;
+            *reinterpret_cast<f32x4*>(d + HS) = sok ? t1 + (f32x4){sv[4], sv[5], sv[6], sv[7]} : z4;
+        }
+        if (i < i_last) load_skip(i + 1, true, i + 1 < zb);
+        __syncthreads();
+        // ---- the whole tile: stencil ----
+        if (de) {            // even plane 2i: completes logit 2i - 1
+            stencil(0, A, B, C);
+            if (i > za) emit(2 * i - 1, A);
+        }
+        A = fresh;
+        if (dodd) {          // odd plane 2i + 1: completes logit 2i
+            stencil(1, B, C, A);
+            if (de) emit(2 * i, B);
+        }
+        const f32x2v t = A;  // (A, B, C) <- logits (2i+1, 2i+2, 2i+3)
+        A = C;
+        B = t;
+        C = fresh;
+        __syncthreads();
+    }
+    if (zb == Di) emit(Do - 1, A);   // the volume's last plane has no successor to complete it
+    (void)Do;
+}
+
 bool conv11_prob_enabled(int dtype) {   // MVS_FUSE_PROB=0: conv11 and prob as two launches (A/B runs)
     static const bool on = [] {
         const char* e = getenv("MVS_FUSE_PROB");
         return !(e && e[0] == '0');
     }();
-    return on && dtype == MVS_F32;
+    // 16-bit storage: the fused kernel runs the transposed convolution on the 16-bit matrix cores, so it stands in
+    // for the 16-bit MFMA layer kernels only (MVS_MFMA16=0 = fp32 arithmetic on the narrowed operands: two launches)
+    return on && (dtype == MVS_F32 || mfma16_enabled());
 }
 
 int launch_conv11_prob(const void* x, const void* skip, float* cost, const float* blob, int Di, int Hi, int Wi,
                        int dtype, hipStream_t s) {
     using namespace cp;
-    if (dtype != MVS_F32) return fail(MVS_ERR_BAD_DTYPE, "conv11_prob: fp32 storage only (dtype %d)", dtype);
+    if (dtype != MVS_F32 && dtype != MVS_F16 && dtype != MVS_BF16)
+        return fail(MVS_ERR_BAD_DTYPE, "conv11_prob: unknown dtype %d", dtype);
     if ((size_t)Di * Hi * Wi * 64 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "conv11_prob: plane exceeds 31-bit offsets");
     const BlobLayout L = blob_layout();
@@ -327,9 +568,20 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
     if (ZC < 4) ZC = 4;
     if (ZC > Di) ZC = Di;
     nzc = (Di + ZC - 1) / ZC;
-    conv11_prob_priv_kernel<MVS_F32><<<nbx * nby * nzc, 512, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
-                                                                      blob + L.w_off[10], blob + L.b_off[10], cost,
-                                                                      Di, Hi, Wi, ZC, nbx, nby);
+    const dim3 grid(nbx * nby * nzc);
+    if (dtype == MVS_F32) {
+        conv11_prob_priv_kernel<MVS_F32><<<grid, 512, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,
+                                                               blob + L.w_off[10], blob + L.b_off[10], cost, Di, Hi, Wi,
+                                                               ZC, nbx, nby);
+    } else {
+        const unsigned short* bp16 = reinterpret_cast<const unsigned short*>(blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][9]);
+        if (dtype == MVS_F16)
+            conv11_prob16_kernel<MVS_F16><<<grid, 512, 0, s>>>(x, bp16, blob + L.b_off[9], skip, blob + L.w_off[10],
+                                                               blob + L.b_off[10], cost, Di, Hi, Wi, ZC, nbx, nby);
+        else
+            conv11_prob16_kernel<MVS_BF16><<<grid, 512, 0, s>>>(x, bp16, blob + L.b_off[9], skip, blob + L.w_off[10],
+                                                                blob + L.b_off[10], cost, Di, Hi, Wi, ZC, nbx, nby);
+    }
     return check_hip(hipGetLastError(), "conv11_prob launch");
 }
 

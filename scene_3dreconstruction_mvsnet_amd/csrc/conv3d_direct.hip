@@ -425,6 +425,15 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
     }
 }
 
+// MVS_MFMA16=0: fp32 MFMA arithmetic on the 16-bit stored operands instead of the 16-bit matrix cores
+bool mfma16_enabled() {
+    static const bool v = [] {
+        const char* e = getenv("MVS_MFMA16");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 // MVS_FORCE_DIRECT=1 routes every layer through the direct kernels (A/B checks in tests).
 static bool force_direct() {
     static const bool v = [] {
@@ -445,11 +454,7 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
     }
     // 16-bit storage: 16-bit MFMA arithmetic (conv3d_mfma16.hip) unless MVS_MFMA16=0 asks for fp32
     // arithmetic on the narrowed operands
-    static const bool mfma16 = [] {
-        const char* e = getenv("MVS_MFMA16");
-        return !(e && e[0] == '0');
-    }();
-    if (mfma16 && (dtype == MVS_F16 || dtype == MVS_BF16) && layer <= 9)
+    if (mfma16_enabled() && (dtype == MVS_F16 || dtype == MVS_BF16) && layer <= 9)
         return launch_layer_mfma16(layer, x, skip, y, blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][layer],
                                    blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     if (layer == 0) {

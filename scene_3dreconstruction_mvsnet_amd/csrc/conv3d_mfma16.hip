@@ -545,15 +545,7 @@ void pack_conv0p16_weights(const float* wfold, int dt, unsigned short* bp) {
 // =============================================================================================
 // deconvg16: conv7 / conv9 / conv11 (+ skip)
 // =============================================================================================
-struct Deconv16Tap { int cls, kz, dz, ky, dy, valid; };
-// k-step ks, combo q (= g>>1): 5 k-steps x 2 (z,y)-tap combos, each with dx = g&1
-__host__ __device__ constexpr Deconv16Tap deconv16_tap(int ks, int q) {
-    return ks == 0 ? (q == 0 ? Deconv16Tap{0, 1, 0, 1, 0, 1} : Deconv16Tap{0, 1, 0, 1, 0, 0})
-         : ks == 1 ? (q == 0 ? Deconv16Tap{1, 1, 0, 2, 0, 1} : Deconv16Tap{1, 1, 0, 0, 1, 1})
-         : ks == 2 ? (q == 0 ? Deconv16Tap{2, 2, 0, 1, 0, 1} : Deconv16Tap{2, 0, 1, 1, 0, 1})
-         : ks == 3 ? (q == 0 ? Deconv16Tap{3, 2, 0, 2, 0, 1} : Deconv16Tap{3, 2, 0, 0, 1, 1})
-                   : (q == 0 ? Deconv16Tap{3, 0, 1, 2, 0, 1} : Deconv16Tap{3, 0, 1, 0, 1, 1});
-}
+// Deconv16Tap / deconv16_tap(ks, q): mvs_internal.h (shared with conv11_prob.hip)
 
 template <int CIN, int COUT, int BZ, int BY, int BX>
 struct DeconvG16 {

@@ -234,8 +234,8 @@ int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const vo
 int mvs_conv11_prob(const void* x, const void* skip, float* cost_out, const void* weights_blob,
                     int Di, int Hi, int Wi, int dtype, void* stream) {
     if (!x || !skip || !cost_out || !weights_blob) return fail(MVS_ERR_NULL, "mvs_conv11_prob: NULL argument");
-    if (dtype != MVS_F32)
-        return fail(MVS_ERR_BAD_DTYPE, "mvs_conv11_prob: fp32 storage only (dtype %d); use mvs_conv_layer 9 and 10", dtype);
+    if (dtype != MVS_F32 && dtype != MVS_F16 && dtype != MVS_BF16)
+        return fail(MVS_ERR_BAD_DTYPE, "mvs_conv11_prob: unknown dtype %d", dtype);
     if (Di < 1 || Hi < 1 || Wi < 1) return fail(MVS_ERR_BAD_SHAPE, "mvs_conv11_prob: input dims %d,%d,%d", Di, Hi, Wi);
     return launch_conv11_prob(x, skip, cost_out, static_cast<const float*>(weights_blob), Di, Hi, Wi, dtype,
                               static_cast<hipStream_t>(stream));

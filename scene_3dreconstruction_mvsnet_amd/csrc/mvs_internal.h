@@ -195,6 +195,18 @@ __host__ __device__ constexpr DeconvStep deconv_step(int ks) {
                    : DeconvStep{3, 0, 1, 0, 1};
 }
 
+// 16-bit (16x16x32 MFMA) form of the same transposed convolution (conv3d_mfma16.hip, conv11_prob.hip): a lane's A
+// fragment is the 8 channels of ONE voxel, lane group g -> dx = g & 1 and (z, y)-tap combo q = g >> 1
+struct Deconv16Tap { int cls, kz, dz, ky, dy, valid; };
+// k-step ks, combo q (= g>>1): 5 k-steps x 2 (z,y)-tap combos, each with dx = g&1
+__host__ __device__ constexpr Deconv16Tap deconv16_tap(int ks, int q) {
+    return ks == 0 ? (q == 0 ? Deconv16Tap{0, 1, 0, 1, 0, 1} : Deconv16Tap{0, 1, 0, 1, 0, 0})
+         : ks == 1 ? (q == 0 ? Deconv16Tap{1, 1, 0, 2, 0, 1} : Deconv16Tap{1, 1, 0, 0, 1, 1})
+         : ks == 2 ? (q == 0 ? Deconv16Tap{2, 2, 0, 1, 0, 1} : Deconv16Tap{2, 0, 1, 1, 0, 1})
+         : ks == 3 ? (q == 0 ? Deconv16Tap{3, 2, 0, 2, 0, 1} : Deconv16Tap{3, 2, 0, 0, 1, 1})
+                   : (q == 0 ? Deconv16Tap{3, 0, 1, 2, 0, 1} : Deconv16Tap{3, 0, 1, 0, 1, 1});
+}
+
 // thread-local error text
 int fail(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
@@ -243,10 +255,11 @@ int launch_convs_mfma(int layer, const void* x, void* y, const float* bp, const 
                       int dtype, hipStream_t s);
 int launch_deconvs_mfma(int layer, const void* x, const void* skip, void* y, const float* bp, const float* bias, int Di,
                         int Hi, int Wi, int dtype, hipStream_t s);
-// conv11 (+ conv0 skip) and prob in one kernel, fp32 storage only (conv11_prob.hip)
+// conv11 (+ conv0 skip) and prob in one kernel (conv11_prob.hip): fp32 storage, or 16-bit storage on the 16-bit MFMA
 int launch_conv11_prob(const void* x, const void* skip, float* cost, const float* blob, int Di, int Hi,
                        int Wi, int dtype, hipStream_t s);
 bool conv11_prob_enabled(int dtype);
+bool mfma16_enabled();   // MVS_MFMA16 != 0
 int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, const void* panel,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out);

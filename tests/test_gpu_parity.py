@@ -155,6 +155,37 @@ def test_fused_conv11_prob_matches_the_two_launches(D, h, w):
     np.testing.assert_array_equal(whole, pair)   # mvs_costreg_forward runs the same kernels on the same inputs
 
 
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
+@pytest.mark.parametrize("D,h,w", [(8, 8, 8), (16, 24, 40), (24, 16, 72)])
+def test_fused_conv11_prob_16bit_matches_oracle(storage, D, h, w):
+    """mvs_conv11_prob with 16-bit storage (transposed convolution on the 16-bit MFMA, prob stencil in fp32 on the
+    never-stored sum): against the oracle with the same rounding points -- x, skip and the BN-folded conv11 weights
+    rounded to the storage dtype, fp32 accumulation, conv11 + skip NOT rounded, fp32 prob (models/mvsnet.py:71-72)
+    -- on shapes with ragged tiles and several z chunks; and against the two 16-bit launches it replaces, which
+    differ from it only by the rounding of the tensor in between."""
+    code = _lib.dtype_code(storage)
+    tdt = _lib.TORCH_DTYPES[code]
+    q = lambda t: orc.round_storage(t, storage)  # noqa: E731
+    sd = synthetic.random_costreg_state(seed=23)
+    blob = blob_for(sd)
+    rng = np.random.default_rng(D * 100 + w)
+    x = q(np.abs(rng.standard_normal((16, D // 2, h // 2, w // 2))).astype(np.float32))
+    skip = q(np.abs(rng.standard_normal((8, D, h, w))).astype(np.float32))
+    wf, sh = orc._fold(sd, "conv11.0.weight", "conv11.1", transposed=True)
+    wt = np.ascontiguousarray(q(wf).transpose(1, 0, 2, 3, 4))
+    d11 = skip + np.maximum(orc.deconv3d(x, wt, bn=None, relu=False) + sh[:, None, None, None], 0.0)
+    want = orc.conv3d(d11, sd["prob.weight"], bias=sd["prob.bias"], bn=None, relu=False)[0]
+    xt, st = _lib.to_c8(cu(x)).to(tdt), _lib.to_c8(cu(skip)).to(tdt)
+    got = _lib.conv11_prob(xt, st, blob, dtype=code).cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = max(float(np.abs(want).max()), 1.0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-5 * scale)    # fp32 summation order only
+    two = _lib.conv_layer(10, _lib.conv_layer(9, xt, st, blob, dtype=code), None, blob, dtype=code).cpu().numpy()
+    eps = {"f16": 2.0 ** -10, "bf16": 2.0 ** -7}[storage]
+    np.testing.assert_allclose(got, two, rtol=0, atol=4 * eps * scale)  # the rounding of d11 the fused form skips
+    assert np.array_equal(got, _lib.conv11_prob(xt, st, blob, dtype=code).cpu().numpy())   # run-to-run identical
+
+
 @pytest.mark.parametrize("layer", list(range(11)))
 def test_every_layer_matches_oracle(layer):
     """mvs_conv_layer for each CostRegNet layer on random C8-planar input vs the oracle."""
