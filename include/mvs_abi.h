@@ -108,10 +108,11 @@ int mvs_costreg_forward(const void* var, const void* weights_blob, float* cost_o
 int mvs_conv_layer(int layer, const void* x, const void* skip, void* y, const void* weights_blob,
                    int Di, int Hi, int Wi, int dtype, void* stream);
 
-/* The last two layers in one kernel (what mvs_costreg_forward runs for fp32 storage): conv11 + BN + ReLU,
- * the conv0 skip add and the prob convolution, without the full-resolution 8-channel tensor in between.
+/* The last two layers in one kernel (what mvs_costreg_forward runs): conv11 + BN + ReLU, the conv0 skip add
+ * and the prob convolution, without the full-resolution 8-channel tensor in between.
  * Replaces models/mvsnet.py:71-72 (`x = conv0 + self.conv11(x); x = self.prob(x)`).  Exported like
- * mvs_conv_layer, for parity tests and per-kernel timing.  MVS_F32 storage only (else MVS_ERR_BAD_DTYPE).
+ * mvs_conv_layer, for parity tests and per-kernel timing.  x and skip in `dtype` (16-bit storage: the transposed
+ * convolution runs on the 16-bit MFMA, the sum that feeds prob stays fp32); the logits are always fp32.
  *   x     dev [2][Di][Hi][Wi][8]  (output of layer 8)     skip  dev [1][2Di][2Hi][2Wi][8]  (output of layer 0)
  *   cost_out  dev fp32 [2Di][2Hi][2Wi] */
 int mvs_conv11_prob(const void* x, const void* skip, float* cost_out, const void* weights_blob,

@@ -20,6 +20,8 @@ dv = torch.from_numpy(synthetic.depth_values(D)).to(dev)
 blob = _lib.pack_weights(synthetic.random_costreg_state(0)).to(dev)
 ws = _lib.alloc_workspace(N, 32, D, h, w, dev)
 rt = _lib.relative_proj(proj)
+if what == "warpz":   # all-zero features: same instruction stream, idle data paths (DVFS / power check)
+    feats = torch.zeros_like(feats)
 var = _lib.warp_variance(feats, rt, dv, ws)
 layer = {"conv0": 0, "conv0z": 0, "conv1": 1, "conv2": 2, "prob": 10}.get(what)
 if what == "conv0z":   # all-zero input: same instruction stream, idle data paths (DVFS / power check)
@@ -27,7 +29,7 @@ if what == "conv0z":   # all-zero input: same instruction stream, idle data path
 
 
 def run():
-    if what == "warp":
+    if what in ("warp", "warpz"):
         _lib.warp_variance(feats, rt, dv, ws)
     else:
         _lib.conv_layer(layer, var if layer == 0 else x_in, None, blob)
