@@ -367,8 +367,7 @@ def main(argv=None):
             stages[name] = ent
     roofline = None
     # which conv0 kernel the library picks (csrc/conv3d_direct.hip): F(4,3) unless told otherwise
-    wino = "0" if os.environ.get("MVS_CONV0_WINO") == "0" else \
-        ("2" if os.environ.get("MVS_CONV0_WINO") == "2" or D % 4 else "4")
+    wino = "0" if (os.environ.get("MVS_CONV0_WINO") == "0" or D % 4) else "4"
     if stages:
         dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
         c, ms = costs[dom], stages[dom]["ms"]
@@ -381,8 +380,8 @@ def main(argv=None):
                         "frac": round(ach / mfma_peak, 4), "traffic": None,
                         "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
                         "algorithmic_bytes": c["bytes"]}
-            if dom == "conv0" and storage == "f32" and wino in ("2", "4"):
-                num, den, form = (1, 2, "F(4,3)") if wino == "4" else (2, 3, "F(2,3)")
+            if dom == "conv0" and storage == "f32" and wino == "4":
+                num, den, form = 1, 2, "F(4,3)"
                 roofline["note"] = (f"conv0 runs Winograd {form} along z on the fp32 4x4x1 MFMA: it issues {num}/{den} "
                                     "of the algorithmic multiply-adds; `achieved` is the ALGORITHMIC flops / time as "
                                     f"SURVEY 8 d3 defines it (it can exceed the MFMA peak), the executed-MFMA rate is "
@@ -402,8 +401,7 @@ def main(argv=None):
             newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]
             with open(newest) as f:
                 prof = json.load(f)["kernels"]
-            want = {"conv0": "conv0_w43_mfma_kernel<0>" if wino == "4" else
-                             ("conv0_wz_mfma_kernel<0>" if wino == "2" else "conv0_4x4_mfma_kernel<0>"),
+            want = {"conv0": "conv0_w43_mfma_kernel<0>" if wino == "4" else "conv0_4x4_mfma_kernel<0>",
                     "warp_variance": "warp_variance_tc2_kernel<0, 0, 4, 4, 0>"}.get(roofline["kernel"], "?")
             ent = next((v for k, v in prof.items() if k.endswith(want)), None)
             if ent:

@@ -1,3 +1,5 @@
+// attic: conv0 with Winograd F(2,3) along z on the 4x4x1 MFMA (the round-1 default, 0.416-0.433 ms at cfg2;
+// superseded by F(4,3), 0.33-0.35 ms: conv_winograd.hip).  Not built.
 // conv0_winograd.hip -- conv0 (32 -> 8 channels, 68 % of the path's FLOPs; reference
 // models/mvsnet.py:36, block models/module.py:26-33) with Winograd F(2,3) along z on the 4x4x1 MFMA.
 //
@@ -24,10 +26,6 @@
 // Results are not bit-equal to an fmaf chain (the sums are re-associated); the difference is a few
 // fp32 ulp per output (tests/test_gpu_parity.py bounds it against the oracle).
 #include "mvs_internal.h"
-#include "storage.h"
-
-namespace mvs {
-
 namespace c0w {
 constexpr int TY = 8, TX = 32;             // output tile: 2 (the z pair) x 8 x 32
 constexpr int HY = TY + 2, HX = TX + 2;
@@ -255,279 +253,6 @@ int launch_conv0_winograd(const void* x, void* y, const float* bw, const float* 
                     (size_t)D * H * W * 8 * 4);
     MVS_DISPATCH_DTYPE(dtype, (run_conv0_wz<DT>(x, y, bw, bias, D, H, W, s)))
 }
-
-// =============================================================================================
-// The same transform for the stride-1 layers conv2 16->16 and conv4 32->32 (models/mvsnet.py:39,42) on v_mfma_f32_16x16x4_f32, built like convg_mfma_kernel (conv3d_mfma.hip):
-// M-tile = 2(y) x 8(x) voxels, N-tile = 16 channels, K-step = 2 taps x 8 channels -- but the block's
-// tile is always two output planes deep, its four halo planes are stored TRANSFORMED, wave t runs the
-// 3x3 (ky,kx) convolution of plane t for all BY x BX M-tiles and all N-tiles (9 taps -> 5 K-steps
-// instead of 27 -> 14 for two planes: 20 vs 28 MFMA quads per M-tile pair), and the four partial
-// results are combined through LDS once per tile.
-// =============================================================================================
-template <int CIN, int COUT, int BY, int BX>
-struct ConvWZ {
-    static constexpr int NT = COUT / 16;
-    static constexpr int MT = BY * BX;
-    static constexpr int NCH = CIN / 8;
-    static constexpr int KS = 5;  // 9 taps padded to 10
-    static constexpr int VS = 8;
-    static constexpr int HY = 2 * BY + 2, HX = 8 * BX + 2;
-    static constexpr int HXP = (HX + 7) / 8 * 8;
-    static constexpr int PLANE = HY * HXP * VS;
-    static constexpr int IN_FLOATS = 4 * PLANE;
-    static constexpr int NCOL = HY * HX * 2;
-    static constexpr int CPT = (NCOL + 255) / 256;
-    static constexpr int NPOS = MT * 16;                  // (y, x) positions of the tile
-    static constexpr int EXS = COUT + 4;                  // floats per position in the exchange tile
-    static constexpr int EX_FLOATS = 4 * NPOS * EXS;
-    static constexpr int TILE_FLOATS = IN_FLOATS > EX_FLOATS ? IN_FLOATS : EX_FLOATS;
-    static constexpr int NUNIT = NPOS * (COUT / 8);       // (position, 8-channel plane) output units
-    static constexpr int UPT = (NUNIT + 255) / 256;
-    static_assert(CPT * 4 <= 32, "too many staged pieces per thread");
-    static constexpr int tap_off(int tap) {
-        const int t = tap > 8 ? 8 : tap;
-        return ((t / 3) * HXP + t % 3) * VS;
-    }
-};
-
-template <int DT, int CIN, int COUT, int BY, int BX>
-__global__ __launch_bounds__(256) void convwz_mfma_kernel(
-    const void* __restrict__ x,      // [CIN/8][D][H][W][8] storage dtype DT
-    const float* __restrict__ bp,    // [NCH][4 t][NT][5][64][4]
-    const float* __restrict__ bias,  // [COUT]
-    void* __restrict__ y,            // [COUT/8][D][H][W][8]
-    int D, int H, int W) {
-    using G = ConvWZ<CIN, COUT, BY, BX>;
-    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
-
-    const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;  // wave t -> transformed plane t
-    const int nbx = (W + 8 * BX - 1) / (8 * BX), nby = (H + 2 * BY - 1) / (2 * BY);
-    int b = blockIdx.x;
-    const int bx = b % nbx; b /= nbx;
-    const int by = b % nby;
-    const int bz = b / nby;
-    const int x0 = bx * 8 * BX, y0 = by * 2 * BY, z0 = bz * 2;
-    const size_t HW8 = (size_t)H * W * 8, V8 = (size_t)D * HW8;
-
-    int goff[G::CPT], loff[G::CPT];
-    unsigned okxy = 0;
-#pragma unroll
-    for (int i = 0; i < G::CPT; ++i) {
-        const int col = tid + i * 256;
-        const int half = col & 1, v = col >> 1;
-        const int hx = v % G::HX, hy = v / G::HX;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = col < G::NCOL && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[i] = ok ? (int)(((size_t)gy * W + gx) * 8 + half * 4) : 0;
-        okxy |= ok ? (1u << i) : 0u;
-        loff[i] = (col < G::NCOL) ? (hy * G::HXP + hx) * G::VS + half * 4 : -1;
-    }
-    size_t zoff[4];
-    bool zok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int gz = z0 - 1 + q;
-        zok[q] = gz >= 0 && gz < D;
-        zoff[q] = zok[q] ? (size_t)gz * HW8 : 0;
-    }
-
-    // A fragment: lane (r -> voxel (ry, rx) of the M-tile, g): k-step ks covers taps 2ks (g>>1 == 0)
-    // and 2ks+1 (g>>1 == 1), channels 4(g&1)..+3 of the chunk
-    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
-    const int ry = r >> 3, rx = r & 7;
-    int abase[G::MT];
-#pragma unroll
-    for (int i = 0; i < G::MT; ++i) {
-        const int tx = i % BX, ty = i / BX;
-        abase[i] = t * G::PLANE + ((2 * ty + ry) * G::HXP + 8 * tx + rx) * G::VS + (g & 1) * 4;
-    }
-    f32x4 acc[G::NT][G::MT];
-#pragma unroll
-    for (int n = 0; n < G::NT; ++n)
-#pragma unroll
-        for (int i = 0; i < G::MT; ++i) acc[n][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 breg[G::NT][G::KS];
-    f32x4 stg[G::CPT][4];
-
-#define WZ_LOAD_B(C)                                                                                 \
-    {                                                                                                \
-        _Pragma("unroll") for (int n = 0; n < G::NT; ++n) {                                          \
-            const f32x4* bsrc = reinterpret_cast<const f32x4*>(bp) +                                 \
-                                ((size_t)(((C) * 4 + t) * G::NT + n) * G::KS) * 64 + lane;           \
-            _Pragma("unroll") for (int ks = 0; ks < G::KS; ++ks) breg[n][ks] = bsrc[ks * 64];        \
-        }                                                                                            \
-    }
-#define WZ_LOAD_A(C)                                                                                 \
-    {                                                                                                \
-        const size_t plane = (size_t)(C) * V8;                                                       \
-        _Pragma("unroll") for (int i = 0; i < G::CPT; ++i)                                           \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                            \
-                stg[i][q] = St<DT>::load4(x, plane + zoff[q] + goff[i]);                             \
-    }
-#define WZ_STORE_A()                                                                                 \
-    {                                                                                                \
-        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};                                              \
-        _Pragma("unroll") for (int i = 0; i < G::CPT; ++i)                                           \
-            if (loff[i] >= 0) {                                                                      \
-                const bool in = (okxy >> i) & 1u;                                                    \
-                const f32x4 d0 = (in && zok[0]) ? stg[i][0] : zero;                                  \
-                const f32x4 d1 = (in && zok[1]) ? stg[i][1] : zero;                                  \
-                const f32x4 d2 = (in && zok[2]) ? stg[i][2] : zero;                                  \
-                const f32x4 d3 = (in && zok[3]) ? stg[i][3] : zero;                                  \
-                *reinterpret_cast<f32x4*>(tile + loff[i]) = d0 - d2;                                 \
-                *reinterpret_cast<f32x4*>(tile + G::PLANE + loff[i]) = d1 + d2;                      \
-                *reinterpret_cast<f32x4*>(tile + 2 * G::PLANE + loff[i]) = d2 - d1;                  \
-                *reinterpret_cast<f32x4*>(tile + 3 * G::PLANE + loff[i]) = d1 - d3;                  \
-            }                                                                                        \
-    }
-
-    WZ_LOAD_B(0)
-    WZ_LOAD_A(0)
-    WZ_STORE_A()
-    __syncthreads();
-
-#pragma unroll 1
-    for (int c = 0; c < G::NCH; ++c) {
-        if (c + 1 < G::NCH) WZ_LOAD_A(c + 1)
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int koff = gh ? G::tap_off(2 * ks + 1) : G::tap_off(2 * ks);
-            f32x4 a[G::MT];
-#pragma unroll
-            for (int i = 0; i < G::MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(tile + abase[i] + koff);
-#pragma unroll
-            for (int n = 0; n < G::NT; ++n) {
-                const f32x4 bq = breg[n][ks];
-#pragma unroll
-                for (int i = 0; i < G::MT; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bq.x, acc[n][i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < G::MT; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bq.y, acc[n][i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < G::MT; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bq.z, acc[n][i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < G::MT; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[n][i], 0, 0, 0);
-            }
-        }
-        if (c + 1 < G::NCH) {
-            WZ_LOAD_B(c + 1)
-            __syncthreads();
-            WZ_STORE_A()
-            __syncthreads();
-        }
-    }
-#undef WZ_LOAD_B
-#undef WZ_LOAD_A
-#undef WZ_STORE_A
-
-    // exchange: D layout col n = lane&15 -> channel 16 nt + n; row m = 4*(lane>>4) + e -> voxel of the
-    // M-tile.  ex[t][pos][channel], pos = 16 * mtile + m.
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < G::NT; ++n)
-#pragma unroll
-        for (int i = 0; i < G::MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = 4 * (lane >> 4) + e;
-                tile[(t * G::NPOS + 16 * i + m) * G::EXS + 16 * n + (lane & 15)] = acc[n][i][e];
-            }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < G::UPT; ++j) {
-        const int u = tid + j * 256;
-        if (u >= G::NUNIT) break;
-        const int pos = u % G::NPOS, pl = u / G::NPOS;
-        const int mt = pos >> 4, m = pos & 15;
-        const int gy = y0 + 2 * (mt / BX) + (m >> 3), gx = x0 + 8 * (mt % BX) + (m & 7);
-        if (gy >= H || gx >= W) continue;
-        f32x4 M[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* e = tile + (q * G::NPOS + pos) * G::EXS + pl * 8;
-            M[q][0] = *reinterpret_cast<const f32x4*>(e);
-            M[q][1] = *reinterpret_cast<const f32x4*>(e + 4);
-        }
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias + pl * 8);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bias + pl * 8 + 4);
-        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            if (z0 + o >= D) break;
-            f32x4 lo, hi;
-            if (o == 0) {
-                lo = (M[0][0] + M[1][0]) + M[2][0] + bv0;
-                hi = (M[0][1] + M[1][1]) + M[2][1] + bv1;
-            } else {
-                lo = (M[1][0] - M[2][0]) - M[3][0] + bv0;
-                hi = (M[1][1] - M[2][1]) - M[3][1] + bv1;
-            }
-            lo = __builtin_elementwise_max(lo, zero);
-            hi = __builtin_elementwise_max(hi, zero);
-            const size_t off = (size_t)pl * V8 + (((size_t)(z0 + o) * H + gy) * W + gx) * 8;
-            if constexpr (DT == MVS_F32) {
-                St<DT>::store4(y, off, lo);
-                St<DT>::store4(y, off + 4, hi);
-            } else {
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                store8_16<DT>(y, off, v);
-            }
-        }
-    }
-}
-
-template <int DT, int CIN, int COUT, int BY, int BX>
-static int run_convwz(const void* x, void* y, const float* bp, const float* bias, int D, int H, int W,
-                      hipStream_t s) {
-    if ((size_t)D * H * W * 8 >= ((size_t)1 << 31))
-        return fail(MVS_ERR_BAD_SHAPE, "convwz_mfma: plane exceeds 31-bit offsets");
-    const int nb = ((W + 8 * BX - 1) / (8 * BX)) * ((H + 2 * BY - 1) / (2 * BY)) * ((D + 1) / 2);
-    convwz_mfma_kernel<DT, CIN, COUT, BY, BX><<<nb, 256, 0, s>>>(x, bp, bias, y, D, H, W);
-    return check_hip(hipGetLastError(), "convwz_mfma launch");
-}
-
-template <int DT>
-static int launch_convwz_dt(int layer, const void* x, void* y, const float* bp, const float* bias, int D,
-                            int H, int W, hipStream_t s) {
-    switch (layer) {
-        case 2: return run_convwz<DT, 16, 16, 4, 2>(x, y, bp, bias, D, H, W, s);
-        case 4: return run_convwz<DT, 32, 32, 2, 2>(x, y, bp, bias, D, H, W, s);
-        default: return fail(MVS_ERR_BAD_SHAPE, "convwz_mfma: layer %d not covered", layer);
-    }
-}
-
-// layers 2, 4 (conv2, conv4)
-int launch_convwz_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int D, int H,
-                       int W, int dtype, hipStream_t s) {
-    MVS_DISPATCH_DTYPE(dtype, (launch_convwz_dt<DT>(layer, x, y, bp, bias, D, H, W, s)))
-}
-
-// wfold [27][cin][cout] -> bp [cin/8][4 t][cout/16][5][64][4], z taps transformed as for conv0
-void pack_convwz_weights(const float* wfold, int cin, int cout, float* bp) {
-    const int nch = cin / 8, nt = cout / 16;
-    for (int c = 0; c < nch; ++c)
-        for (int t = 0; t < 4; ++t)
-            for (int n = 0; n < nt; ++n)
-                for (int ks = 0; ks < 5; ++ks)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j4 = 0; j4 < 4; ++j4) {
-                            const int g = lane >> 4, col = lane & 15;
-                            const int tap = 2 * ks + (g >> 1);
-                            const int ci = 8 * c + 4 * (g & 1) + j4, co = 16 * n + col;
-                            float v = 0.0f;
-                            if (tap < 9) {
-                                const float g0 = wfold[((size_t)(0 * 9 + tap) * cin + ci) * cout + co];
-                                const float g1 = wfold[((size_t)(1 * 9 + tap) * cin + ci) * cout + co];
-                                const float g2 = wfold[((size_t)(2 * 9 + tap) * cin + ci) * cout + co];
-                                v = t == 0 ? g0 : t == 1 ? ((g0 + g1) + g2) * 0.5f
-                                  : t == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
-                            }
-                            bp[(((((size_t)c * 4 + t) * nt + n) * 5 + ks) * 64 + lane) * 4 + j4] = v;
-                        }
-}
-
-size_t convwz_panel_floats(int cin, int cout) { return (size_t)(cin / 8) * 4 * (cout / 16) * 5 * 64 * 4; }
-
-// wfold [27][32][8] (tap = kz*9 + ky*3 + kx) -> bw [4 chunks][4 t][9][2 halves][2 nt][4 j][4 k] with
 // the z taps transformed: G0 = g0, G1 = (g0+g1+g2)/2, G2 = (g0-g1+g2)/2, G3 = g2
 void pack_conv0_winograd_weights(const float* wfold, float* bw) {
     for (int c = 0; c < 4; ++c)
@@ -547,4 +272,3 @@ void pack_conv0_winograd_weights(const float* wfold, float* bw) {
                             }
 }
 
-}  // namespace mvs

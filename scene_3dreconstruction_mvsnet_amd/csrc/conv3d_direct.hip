@@ -458,21 +458,18 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         return launch_layer_mfma16(layer, x, skip, y, blob + L.h16_off[dtype == MVS_F16 ? 0 : 1][layer],
                                    blob + L.b_off[layer], Di, Hi, Wi, dtype, s);
     if (layer == 0) {
-        // conv0: Winograd along z on the 4x4x1 MFMA -- F(4,3) (1/2 of the direct form's MFMAs, default) or
-        // F(2,3) (2/3; MVS_CONV0_WINO=2) -- unless MVS_CONV0_WINO=0 asks for the direct form
-        static const int wino = [] {
+        // conv0: Winograd F(4,3) along z on the 4x4x1 MFMA (1/2 of the direct form's MFMAs; conv_winograd.hip)
+        // unless MVS_CONV0_WINO=0 asks for the direct form (cross-check) or the volume needs 64-bit offsets
+        static const bool wino = [] {
             const char* e = getenv("MVS_CONV0_WINO");
-            return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 4;
+            return !(e && e[0] == '0');
         }();
-        const bool fits = (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31);   // else: direct kernel (64-bit offsets)
-        if (wino >= 4 && fits && Di % 4 == 0)
+        if (wino && Di % 4 == 0 && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31))
             return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
-        if (wino && fits)
-            return launch_conv0_winograd(x, y, blob + L.c0w_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
         return launch_conv0_mfma(x, y, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
     }
     if (layer == 2 || layer == 4) {
-        // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv0_winograd.hip) unless
+        // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv_winograd.hip) unless
         // MVS_CONV_WINO=0.  conv6 (64 -> 64 on 7,680 voxels) stays direct: with two-plane tiles it has
         // only 240 blocks for 256 CUs and measured 0.035 vs 0.033 ms.
         static const bool wz = [] {

@@ -42,9 +42,8 @@ struct BlobLayout {
     size_t c0q_off;                // conv0 4x4x1 panel [4][27][2][2][4][4] (conv3d_mfma.hip)
     size_t gp_off[MVS_NUM_LAYERS]; // generic MFMA panels of layers 1..6 and deconv panels of 7..9
     size_t h16_off[2][10];         // 16-bit MFMA panels of layers 0..9 for MVS_F16 ([0]) / MVS_BF16 ([1])
-    size_t c0w_off;                // conv0 Winograd-z panel [4][4][9][2][2][4][4] (conv0_winograd.hip)
-    size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv0_winograd.hip)
-    size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv0_wino43.hip)
+    size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv_winograd.hip)
+    size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv_winograd.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -76,8 +75,6 @@ inline BlobLayout blob_layout() {
             L.h16_off[d][l] = off;
             off += (elems / 2 + 63) & ~(size_t)63;
         }
-    L.c0w_off = off;
-    off += (size_t)4 * 4 * 9 * 2 * 2 * 4 * 4;
     for (int l = 2; l <= 4; l += 2) {
         L.wz_off[l] = off;
         off += (size_t)(kLayers[l].cin / 8) * 4 * (kLayers[l].cout / 16) * 5 * 64 * 4;
@@ -231,9 +228,6 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
                       int Di, int Hi, int Wi, int dtype, hipStream_t s);
 int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y, const float* wgt,
                              const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
-int launch_conv0_winograd(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
-                          int dtype, hipStream_t s);
-void pack_conv0_winograd_weights(const float* wfold, float* bw);
 int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                         int dtype, hipStream_t s);
 void pack_conv0_wino43_weights(const float* wfold, float* bw);

@@ -297,7 +297,6 @@ def test_nonfinite_coordinates_give_nan_like_torch():
 
 @pytest.mark.parametrize("env", [
     {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off; also the N > 5 path)
-    {"MVS_CONV0_WINO": "2"},     # conv0 with Winograd F(2,3) along z instead of F(4,3)
     {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches

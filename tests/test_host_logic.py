@@ -125,16 +125,6 @@ def test_pack_weights_folds_bn_and_relayouts():
                         bits = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
                     assert panel[c, t, ks, lane, j] == bits
             off += (elems // 2 + 63) // 64 * 64
-    # conv0 Winograd-z panel [4 chunks][4 t][9 taps][2 halves][2 nt][4 j][4 k]: the z taps transformed
-    # G0 = g0, G1 = (g0+g1+g2)/2, G2 = (g0-g1+g2)/2, G3 = g2   (conv0_winograd.hip)
-    wz = blob[off:off + 4 * 4 * 9 * 2 * 2 * 4 * 4].reshape(4, 4, 9, 2, 2, 4, 4)
-    g = blob[:27 * 32 * 8].reshape(3, 9, 32, 8).astype(np.float64)   # [kz][ky*3+kx][ci][co]
-    G = [g[0], (g[0] + g[1] + g[2]) / 2, (g[0] - g[1] + g[2]) / 2, g[2]]
-    for c, t, tap, half, nt, j, k in [(0, 0, 0, 0, 0, 0, 0), (3, 3, 8, 1, 1, 3, 3), (1, 1, 4, 0, 1, 2, 1),
-                                      (2, 2, 5, 1, 0, 1, 3)]:
-        np.testing.assert_allclose(wz[c, t, tap, half, nt, j, k], G[t][tap, 8 * c + 4 * half + k, 4 * nt + j],
-                                   rtol=1e-6, atol=1e-9)
-    off += 4 * 4 * 9 * 2 * 2 * 4 * 4
     # Winograd-z panels of the stride-1 layers 2 and 4: [cin/8][4 t][cout/16][5 k-steps][64 lanes][4]
     for l in (2, 4):
         ci, co = layer_ch[l]
@@ -149,7 +139,7 @@ def test_pack_weights_folds_bn_and_relayouts():
             want = Gl[t][tap, 8 * c + 4 * (g & 1) + j4, 16 * n + col] if tap < 9 else 0.0
             np.testing.assert_allclose(panel[c, t, n, ks, lane, j4], want, rtol=1e-6, atol=1e-9)
         off += nch * 4 * nt * 5 * 256
-    # conv0 Winograd F(4,3)-z panel [4 chunks][6 t][9 taps][2 halves][2 nt][4 j][4 k] (conv0_wino43.hip)
+    # conv0 Winograd F(4,3)-z panel [4 chunks][6 t][9 taps][2 halves][2 nt][4 j][4 k] (conv_winograd.hip)
     w43 = blob[off:off + 4 * 6 * 9 * 2 * 2 * 4 * 4].reshape(4, 6, 9, 2, 2, 4, 4)
     g = blob[:27 * 32 * 8].reshape(3, 9, 32, 8).astype(np.float64)
     G43 = [g[0] / 4, -(g[0] + g[1] + g[2]) / 6, -(g[0] - g[1] + g[2]) / 6,
