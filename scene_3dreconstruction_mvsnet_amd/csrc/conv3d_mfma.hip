@@ -21,6 +21,7 @@
 
 namespace mvs {
 
+typedef unsigned u32x4r __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 // Diagnostic builds only (make ABLATE=n -> libmvs_hip_ablate<n>.so, wrong results by design):
 //   1 = conv0 without epilogue stores, 2 = without chunk re-staging, 3 = also without the
@@ -619,11 +620,221 @@ static int run_convg_persist(const void* x, void* y, const float* bp, const floa
     return check_hip(hipGetLastError(), "convg_mfma launch");
 }
 
+// =============================================================================================
+// conv1 (8 -> 16, stride 2: models/mvsnet.py:38) as a z-MARCHING kernel, fp32 storage (round 3).
+//
+// conv1 reads the largest activation of the net (conv0's output: 126 MB at cfg2) to do 3.4 GFLOP: its floor is
+// HBM and MFMA at once (20 / 21.6 us).  The tile kernel above re-stages a 3 x 9 x 33 halo per 1 x 4 x 16 outputs
+// (1.74x the input through L2 -> LDS), a single 56-MFMA chunk per wave per tile: 0.052 ms even as persistent
+// blocks.  Here a 512-thread block owns an 8 x 16 (y, x) column of the OUTPUT and marches along z: per output
+// plane two new input planes enter a ring of five in LDS (17 x 33 voxels each, halo only in y / x: 1.10x), requested
+// up to three steps ahead into three rotating register sets (bytes in flight are what the kernel needs, see
+// conv0z16 in conv3d_mfma16.hip); wave w owns one 2 x 8 M-tile, the 14-k-step panel (one chunk) stays in registers:
+// 56 MFMAs per wave and step, one block barrier per step.  Voxel stride 32 B (not the 48 B the tile kernels use
+// for stride 2): with the row pitch = 1 (mod 8) sixteen-byte slots the lane groups of ds_read_b128 cover 16
+// distinct slots ({0,4,8,12}, {2,6,10,14} for the second row, +1 for the other channel half).  Every VMEM
+// instruction is unconditional (clamped plane, out-of-range store offset): hipcc then keeps counted vmcnt waits.
+// Epilogue through a wave-private LDS strip into 16-byte stores (one per lane).  Same panel, same k order as
+// convg_mfma_kernel: identical results.
+// =============================================================================================
+namespace c1z {
+constexpr int TYO = 8, TXO = 16;                 // output tile: 4 x 2 M-tiles of 2 x 8
+constexpr int HY = 2 * TYO + 1, HX = 2 * TXO + 1;
+constexpr int PITCH = 73 * 4;                    // floats per row: 73 sixteen-byte slots (66 used)
+constexpr int SLOT = HY * PITCH;                 // one input plane (8 channels): 19.9 KB
+constexpr int RING = 5;
+constexpr int THREADS = 512;
+constexpr int NPIECE = HY * HX * 2;              // 16-byte pieces of one plane
+constexpr int PPT = (NPIECE + THREADS - 1) / THREADS;   // 3
+constexpr int STRIP = 16 * 20;                   // epilogue strip per wave: [voxel 16][20 floats]
+}  // namespace c1z
+
+__global__ __launch_bounds__(c1z::THREADS) void conv1z_mfma_kernel(
+    const float* __restrict__ x,     // [1][Di][Hi][Wi][8]
+    const float* __restrict__ bp,    // [1][1][14][64][4]
+    const float* __restrict__ bias,  // [16]
+    float* __restrict__ y,           // [2][Do][Ho][Wo][8]
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ZC, int nbx, int nby) {
+    using namespace c1z;
+    __shared__ __attribute__((aligned(16))) float ring[RING * SLOT];
+    __shared__ __attribute__((aligned(16))) float strips[8 * STRIP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b;
+    {   // XCD k works through the k-th eighth of the (z chunk, row, column) sequence (blockIdx % 8 names the XCD)
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ox0 = bx * TXO, oy0 = by * TYO;
+    const int za = bz * ZC, zb = min(za + ZC, Do);
+    const int ix0 = 2 * ox0 - 1, iy0 = 2 * oy0 - 1;
+    const size_t HW8 = (size_t)Hi * Wi * 8;
+
+    // staging: piece p = tid + i * THREADS -> (hy, hx, half) of a plane
+    size_t goff[PPT];
+    int loff[PPT];
+    unsigned okxy = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * THREADS;
+        const int half = p & 1, v = p >> 1;
+        const int hx = v % HX, hy = v / HX;
+        const int gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = p < NPIECE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        goff[i] = ok ? ((size_t)gy * Wi + gx) * 8 + half * 4 : 0;
+        okxy |= ok ? (1u << i) : 0u;
+        loff[i] = p < NPIECE ? hy * PITCH + hx * 8 + half * 4 : -1;
+    }
+    auto load_plane = [&](int gz, f32x4 (&st)[PPT]) {   // raw loads (plane clamped into the volume); masked when stored
+        const size_t zo = (size_t)min(max(gz, 0), Di - 1) * HW8;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) st[i] = *reinterpret_cast<const f32x4*>(x + goff[i] + zo);
+    };
+    auto slot_of = [&](int gz) { return ((gz + 1) % RING) * SLOT; };   // gz >= -1
+    auto store_plane = [&](int gz, const f32x4 (&st)[PPT]) {
+        float* slot = ring + slot_of(gz);
+        const bool zok = gz >= 0 && gz < Di;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (loff[i] >= 0)
+                *reinterpret_cast<f32x4*>(slot + loff[i]) = (zok && ((okxy >> i) & 1u)) ? st[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // the panel in registers
+    f32x4 breg[14];
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks) breg[ks] = reinterpret_cast<const f32x4*>(bp)[ks * 64 + lane];
+
+    // A fragment: lane (r -> voxel (ry, rx) of the M-tile, g): taps 2ks (g>>1 == 0) / 2ks+1, channels 4(g&1)..+3
+    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
+    const int tyw = wave >> 1, txw = wave & 1;
+    const int abase = (2 * (2 * tyw + (r >> 3))) * PITCH + (2 * (8 * txw + (r & 7))) * 8 + (g & 1) * 4;
+    int kin[14];   // within-plane offset of this lane's tap of k-step ks
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks) {
+        const int t0 = 2 * ks, t1 = 2 * ks + 1 > 26 ? 26 : 2 * ks + 1;
+        const int o0 = ((t0 / 3) % 3) * PITCH + (t0 % 3) * 8, o1 = ((t1 / 3) % 3) * PITCH + (t1 % 3) * 8;
+        kin[ks] = abase + (gh ? o1 : o0);
+    }
+    const int n = lane & 15;
+    const float bv = bias[n];
+    float* strip = strips + wave * STRIP;
+    // epilogue store role: lane -> piece (voxel = lane >> 2, channels 4 (lane & 3) ..)
+    const int sv = lane >> 2, sq = lane & 3;
+    const int sgy = oy0 + 2 * tyw + (sv >> 3), sgx = ox0 + 8 * txw + (sv & 7);
+    const bool st_ok = sgy < Ho && sgx < Wo;
+    const size_t Vout8 = (size_t)Do * Ho * Wo * 8;
+    const unsigned st_off = (unsigned)((((size_t)(sq >> 1) * Vout8) + ((size_t)sgy * Wo + sgx) * 8 + (sq & 1) * 4) * 4);
+    const unsigned zstep_b = (unsigned)((size_t)Ho * Wo * 8 * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, (short)0, (int)(unsigned)(2 * Vout8 * 4), 0x00020000);
+
+    // prologue: input planes 2za-1, 2za, 2za+1 into the ring; the planes of steps za (2za+2, 2za+3) and za+1 in flight
+    // (all seven planes requested back to back: one round trip in front of the first MFMA, not two)
+    f32x4 a0[PPT], a1[PPT], b0[PPT], b1[PPT], c0[PPT], c1[PPT];
+    {
+        f32x4 t0[PPT];
+        load_plane(2 * za - 1, c0);
+        load_plane(2 * za, c1);
+        load_plane(2 * za + 1, t0);
+        load_plane(2 * za + 2, a0);
+        load_plane(2 * za + 3, a1);
+        load_plane(2 * za + 4, b0);
+        load_plane(2 * za + 5, b1);
+        store_plane(2 * za - 1, c0);
+        store_plane(2 * za, c1);
+        store_plane(2 * za + 1, t0);
+    }
+    __syncthreads();
+
+    // one output plane zo: (n0, n1) receive input planes 2zo+6, 2zo+7 (first read in step zo+3), (w0, w1) hold planes
+    // 2zo+2, 2zo+3 (requested two steps ago) and go into the slots of planes 2zo-3, 2zo-2, which no step reads any more
+    auto step = [&](int zo, f32x4 (&w0)[PPT], f32x4 (&w1)[PPT], f32x4 (&n0)[PPT], f32x4 (&n1)[PPT]) {
+        load_plane(2 * zo + 6, n0);
+        load_plane(2 * zo + 7, n1);
+        int sb[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) sb[kz] = slot_of(2 * zo - 1 + kz);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const int t0 = 2 * ks, t1 = 2 * ks + 1 > 26 ? 26 : 2 * ks + 1;
+            const int s = (t0 / 9 == t1 / 9) ? sb[t0 / 9] : (gh ? sb[t1 / 9] : sb[t0 / 9]);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ring + s + kin[ks]);
+            const f32x4 bq = breg[ks];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+        }
+        // epilogue: row m = 4 g + e of the M-tile, column n -> strip[m][n]; then one 16-byte piece per lane
+#pragma unroll
+        for (int e = 0; e < 4; ++e) strip[(4 * g + e) * 20 + n] = fmaxf(acc[e] + bv, 0.0f);
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 o = *reinterpret_cast<const f32x4*>(strip + sv * 20 + sq * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, o), yrs,
+                                               (int)((st_ok && zo < zb) ? st_off + (unsigned)zo * zstep_b : 0xFFFFFFF0u), 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        store_plane(2 * zo + 2, w0);
+        store_plane(2 * zo + 3, w1);
+        __syncthreads();
+    };
+    int zo = za;
+#pragma unroll 1
+    for (; zo + 3 <= zb; zo += 3) {
+        step(zo, a0, a1, c0, c1);
+        step(zo + 1, b0, b1, a0, a1);
+        step(zo + 2, c0, c1, b0, b1);
+    }
+    if (zo < zb) {   // the one or two planes left over (the register sets are back in their first order)
+        step(zo, a0, a1, c0, c1);
+        if (zo + 1 < zb) step(zo + 1, b0, b1, a0, a1);
+    }
+}
+
+static int run_conv1z(const void* x, void* y, const float* bp, const float* bias, int Di, int Hi, int Wi, int Do, int Ho,
+                      int Wo, hipStream_t s) {
+    using namespace c1z;
+    const int nbx = (Wo + TXO - 1) / TXO, nby = (Ho + TYO - 1) / TYO, ncol = nbx * nby;
+    int cus = persistent_blocks_per_cu_scale();
+    // z chunks (>= 4 output planes; each chunk re-reads one input plane and pays a prologue of about two steps): the
+    // split that fills the last round of one-block-per-CU best
+    int best = 1;
+    double best_eff = 0.0;
+    for (int nz = 1; nz <= (Do + 3) / 4; ++nz) {
+        const int zc = (Do + nz - 1) / nz, nzc = (Do + zc - 1) / zc;
+        const long nb = (long)ncol * nzc;
+        const double eff = (double)nb / (double)(((nb + cus - 1) / cus) * cus) * zc / (zc + 2.5);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+    }
+    const int ZC = (Do + best - 1) / best, nzc = (Do + ZC - 1) / ZC;
+    conv1z_mfma_kernel<<<ncol * nzc, THREADS, 0, s>>>(static_cast<const float*>(x), bp, bias, static_cast<float*>(y), Di, Hi,
+                                                      Wi, Do, Ho, Wo, ZC, nbx, nby);
+    return check_hip(hipGetLastError(), "conv1z_mfma launch");
+}
+
 template <int DT>
 static int launch_convg_dt(int layer, const void* x, void* y, const float* bp, const float* bias, int Di,
                            int Hi, int Wi, hipStream_t s) {
     switch (layer) {
-        case 1: return run_convg_persist<DT, 8, 16, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 1: {
+            // fp32 storage, a volume whose (y, x) columns fill the chip: the z-marching kernel (MVS_CONV1Z=0/1 = never /
+            // always); else the persistent tile kernel
+            if constexpr (DT == MVS_F32) {
+                static const int zm = [] {
+                    const char* e = getenv("MVS_CONV1Z");
+                    return e ? atoi(e) : -1;
+                }();
+                const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+                const long ncol = (long)((Wo + c1z::TXO - 1) / c1z::TXO) * ((Ho + c1z::TYO - 1) / c1z::TYO);
+                if (zm != 0 && (size_t)Do * Ho * Wo * 16 * 4 < ((size_t)1 << 32) - 64 && (size_t)Di * Hi * Wi * 8 < ((size_t)1 << 31) &&
+                    (zm == 1 || ncol * ((Do + 3) / 4) >= persistent_blocks_per_cu_scale() / 2))
+                    return run_conv1z(x, y, bp, bias, Di, Hi, Wi, Do, Ho, Wo, s);
+            }
+            return run_convg_persist<DT, 8, 16, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        }
         case 2: return run_convg<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 3: return run_convg<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 4: return run_convg<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);

@@ -355,6 +355,11 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_CONV0Z16": "1"}, ("24", "24", "40", "f16", "bf16")),
     ({"MVS_CONV0Z16": "1"}, ("16", "16", "32", "bf16")),
     ({"MVS_CONV0Z16": "0"}, ("16", "16", "32", "f16")),
+    # z-marching fp32 conv1 (conv3d_mfma.hip: default once its columns fill the chip): several z chunks with
+    # surplus steps, ragged y / x tiles (h/2 = 12 rows for 8-row tiles, w/2 = 20 for 16-column tiles)
+    ({"MVS_CONV1Z": "1"}, ("24", "24", "40", "f32")),
+    ({"MVS_CONV1Z": "1"}, ("16", "16", "32", "f32")),
+    ({"MVS_CONV1Z": "0"}, ("16", "16", "32", "f32")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a
