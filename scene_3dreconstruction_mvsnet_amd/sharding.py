@@ -106,13 +106,35 @@ def rank_cpus(local_rank: int, local_world: int, allowed: list, gpu_cpus: list |
     return allowed[local_rank * n // local_world:(local_rank + 1) * n // local_world]
 
 
+def visible_gpu_order(n_physical: int, environ=None) -> list:
+    """Physical indices of the GPUs this process sees, in the order HIP numbers them: the launcher may have
+    narrowed or permuted them with ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (integer
+    lists; anything else -- UUIDs, an empty value -- leaves the physical order)."""
+    import os
+    env = os.environ if environ is None else environ
+    order = list(range(n_physical))
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):   # applied in this order
+        val = env.get(name)
+        if not val:
+            continue
+        try:
+            idx = [int(t) for t in val.split(",") if t.strip() != ""]
+        except ValueError:
+            continue
+        if idx and all(0 <= i < len(order) for i in idx):
+            order = [order[i] for i in idx]
+    return order
+
+
 def pin_rank(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> list:
     """Pin the calling process to its rank's cores (call BEFORE the first GPU call so that the runtime's
     helper threads inherit the mask).  Returns the cores; [] when the platform has no affinity API."""
     import os
     if not hasattr(os, "sched_setaffinity") or local_world <= 1:
         return []
-    cpus = rank_cpus(local_rank, local_world, sorted(os.sched_getaffinity(0)), gpu_local_cpus(sysfs_root))
+    gpus = gpu_local_cpus(sysfs_root)
+    gpus = [gpus[i] for i in visible_gpu_order(len(gpus))]
+    cpus = rank_cpus(local_rank, local_world, sorted(os.sched_getaffinity(0)), gpus)
     if cpus:
         os.sched_setaffinity(0, cpus)
     return cpus

@@ -442,3 +442,9 @@ def test_rank_cpus_follow_the_gpu_numa_node(tmp_path):
     assert sharding.rank_cpus(0, 4, [40, 41, 42, 43], gpus) == [40]
     assert sharding.rank_cpus(3, 8, [0, 1], None) == [0, 1]       # fewer cores than ranks: share them
     assert sharding.pin_rank(0, 1) == []                          # a single rank is never pinned
+    # the launcher may narrow / permute the visible devices: LOCAL_RANK counts the VISIBLE ones
+    assert sharding.visible_gpu_order(4, {}) == [0, 1, 2, 3]
+    assert sharding.visible_gpu_order(4, {"HIP_VISIBLE_DEVICES": "2,3"}) == [2, 3]
+    assert sharding.visible_gpu_order(8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1,0"}) == [5, 4]
+    assert sharding.visible_gpu_order(4, {"HIP_VISIBLE_DEVICES": "GPU-abc"}) == [0, 1, 2, 3]
+    assert sharding.visible_gpu_order(2, {"CUDA_VISIBLE_DEVICES": "0,5"}) == [0, 1]     # out of range: ignored
