@@ -561,13 +561,23 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
-    // z chunks: as many as keep every block resident at once (two per CU), at least 4 input planes each
-    int nzc = (2 * cus) / (nbx * nby);
-    if (nzc < 1) nzc = 1;
-    int ZC = (Di + nzc - 1) / nzc;
+    // z chunks of >= 4 input planes (every chunk recomputes one input plane and pays a prologue of about half a step):
+    // the split that fills the last round of two-blocks-per-CU best.  (Round 2 took the largest split that keeps all
+    // blocks resident at once: fine at cfg2 (60 tiles x 8 chunks = 480 blocks for 512 slots), 57 % at cfg3 (294 tiles,
+    // ONE chunk of 128 planes each).)
+    const int ntile = nbx * nby, slots = 2 * cus;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int nz = 1; nz <= (Di + 3) / 4; ++nz) {
+        const int zc = (Di + nz - 1) / nz, nzc_ = (Di + zc - 1) / zc;
+        const long nb = (long)ntile * nzc_;
+        const double eff = (double)nb / (double)(((nb + slots - 1) / slots) * slots) * zc / (zc + 1.5);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+    }
+    int ZC = (Di + best - 1) / best;
     if (ZC < 4) ZC = 4;
     if (ZC > Di) ZC = Di;
-    nzc = (Di + ZC - 1) / ZC;
+    const int nzc = (Di + ZC - 1) / ZC;
     const dim3 grid(nbx * nby * nzc);
     if (dtype == MVS_F32) {
         conv11_prob_priv_kernel<MVS_F32><<<grid, 512, 0, s>>>(x, blob + L.gp_off[9], blob + L.b_off[9], skip,

@@ -411,11 +411,11 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
     constexpr int pix = 256 / (32 / CPT);
     constexpr size_t fes = FDT == MVS_F32 ? 4 : 2;
     // all views' features against the 32 MB of aggregate L2 (MVS_WARP_DEPTH_FASTEST=1 forces the order)
-    static const bool force_df = [] {
+    static const int force_df = [] {   // 1 = always, 0 = never (A/B runs), unset = by size
         const char* e = getenv("MVS_WARP_DEPTH_FASTEST");
-        return e && e[0] == '1';
+        return e ? atoi(e) : -1;
     }();
-    const int df = (force_df || (size_t)N * h * w * 32 * fes > ((size_t)24 << 20)) ? 1 : 0;
+    const int df = force_df >= 0 ? force_df : ((size_t)N * h * w * 32 * fes > ((size_t)24 << 20) ? 1 : 0);
     const unsigned npb = (h * w + pix - 1) / pix, nsl = (D + slab - 1) / slab;
     const dim3 grid = df ? dim3(nsl, npb) : dim3(npb, nsl);
     // PAIR = 1: one projection pass per two depth steps (quad q of a pixel evaluates depth d + q)
