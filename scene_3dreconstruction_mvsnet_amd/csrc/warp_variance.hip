@@ -27,38 +27,51 @@ namespace mvs {
 
 // ---------------------------------------------------------------------------------------------
 // rt[v-1] = rows 0..2 of proj[v] @ inverse(proj[0])      (models/module.py:107-109)
-// One thread per source view; Gauss-Jordan with partial pivoting in fp64, rounded to fp32.
+// One thread per source view.  inverse(proj[0]) by cofactors in fp64 (adjugate / determinant), rounded to fp32
+// at the end: branch-free and fully unrolled, so the 4x4 system stays in registers -- the Gauss-Jordan form with
+// partial pivoting indexed its rows dynamically (scratch memory) and made this side block the longest-running
+// block of the transpose launch (12.4 us for 6 us of transposing).  A singular ref_proj gives inf / NaN like
+// torch.inverse's result would.
 // ---------------------------------------------------------------------------------------------
 __device__ void relative_proj_view(const float* __restrict__ proj, float* __restrict__ rt, int N, int v) {
     if (v >= N) return;
-    double a[4][8];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = (double)proj[i * 4 + j];
-            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int col = 0; col < 4; ++col) {
-        int piv = col;
-        double best = fabs(a[col][col]);
-        for (int r = col + 1; r < 4; ++r)
-            if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
-        if (piv != col)
-            for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
-        const double inv = 1.0 / a[col][col];  // singular ref_proj -> inf/NaN, as torch.inverse
-        for (int j = 0; j < 8; ++j) a[col][j] *= inv;
-        for (int r = 0; r < 4; ++r) {
-            if (r == col) continue;
-            const double f = a[r][col];
-            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
-        }
-    }
+    double m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = (double)proj[i];
+    // 2x2 minors of rows (0,1) and rows (2,3)
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double id = 1.0 / det;
+    double inv[16];
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
     const float* ps = proj + (size_t)v * 16;
     float* o = rt + (size_t)(v - 1) * 12;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         double row[4];
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             double acc = 0.0;
-            for (int k = 0; k < 4; ++k) acc += (double)ps[i * 4 + k] * a[k][4 + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += (double)ps[i * 4 + k] * inv[k * 4 + j];
             row[j] = acc;
         }
         o[i * 3 + 0] = (float)row[0];
