@@ -282,6 +282,23 @@ def test_depth_infer_matches_oracle_random(N, h, w, D, kw):
     assert_conf_close(conf, conf_o, idx_o, prob=prob_o, atol=1e-3)
 
 
+@pytest.mark.parametrize("D,h,w,gain", [(8, 5, 7, 1.0), (48, 12, 20, 3.0), (192, 16, 24, 1.0), (256, 8, 40, 10.0),
+                                         (272, 8, 24, 3.0), (17, 3, 5, 30.0)])
+def test_softargmin_conf_random_logits(D, h, w, gain):
+    """mvs_softargmin_conf on random logits against the oracle (models/mvsnet.py:192-218): the register-resident
+    form (D <= 128: 8 logits per thread, D <= 256: 16) and the looping form (D = 272), ragged pixel blocks (h*w not
+    a multiple of 16), D not a multiple of the 16 slices, sharp and flat distributions; the confidence window
+    straddling two slices is summed through LDS."""
+    rng = np.random.default_rng(D * 31 + w)
+    cost = (gain * rng.standard_normal((D, h, w))).astype(np.float32)
+    dv = synthetic.depth_values(D)
+    depth_o, conf_o, idx_o, prob_o = orc.softargmin_conf(cost, dv, want_prob=True)
+    depth, conf = _lib.softargmin_conf(cu(cost), cu(dv))
+    depth, conf = depth.cpu().numpy(), conf.cpu().numpy()
+    assert rel_l1(depth, depth_o) < 2e-6
+    assert_conf_close(conf, conf_o, idx_o, prob=prob_o, atol=2e-5)
+
+
 def test_nonfinite_coordinates_give_nan_like_torch():
     C, h, w = 32, 8, 8
     fea = np.ones((1, C, h, w), np.float32)
