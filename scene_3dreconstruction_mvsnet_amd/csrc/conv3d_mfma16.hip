@@ -380,8 +380,13 @@ __global__ __launch_bounds__(256) void conv0p16_mfma_kernel(
 //     LDS operations execute in order) and leaves as 16-byte stores, one voxel per lane.
 // Same panel and same k order as conv0p16 (chunk-major, then kz, ky): identical results.
 // =============================================================================================
+// C0Z_TY = rows (= waves) per block: 8 -> one block per CU (default); 4 -> two independent 4-wave blocks per CU
+// (-DC0Z_TY=4) measured slower: 0.632 vs 0.590 ms at cfg3, 0.0876 vs 0.0818 at cfg5 (halo 1.5x instead of 1.25x in y)
+#ifndef C0Z_TY
+#define C0Z_TY 8
+#endif
 namespace c0z {
-constexpr int TY = 8, TX = 32, HY = TY + 2, HX = TX + 2;
+constexpr int TY = C0Z_TY, TX = 32, HY = TY + 2, HX = TX + 2;
 constexpr int CH = HY * HX * 8;                  // 16-bit elements of one chunk of one plane
 constexpr int SLOT = 4 * CH;                     // one plane: [chunk][hy][hx][8]
 constexpr int RING = 4;
@@ -756,7 +761,8 @@ static int launch_layer16_dt(int layer, const void* x, const void* skip, void* y
             for (int nz = 1; nz <= Di / 8; ++nz) {
                 const int zc = (Di + nz - 1) / nz, nzc = (Di + zc - 1) / zc;
                 const long nb = (long)ncol * nzc;
-                const double eff = (double)nb / (double)(((nb + cus - 1) / cus) * cus) * zc / (zc + 2.0);
+                const long slots = (long)cus * (8 / c0z::TY);   // blocks resident at once
+                const double eff = (double)nb / (double)(((nb + slots - 1) / slots) * slots) * zc / (zc + 2.0);
                 if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
             }
             const int ZC = (Di + best - 1) / best, nzc = (Di + ZC - 1) / ZC;
