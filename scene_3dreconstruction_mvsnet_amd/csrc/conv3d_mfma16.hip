@@ -532,6 +532,254 @@ __global__ __launch_bounds__(c0z::THREADS) void conv0z16_mfma_kernel(
     }
 }
 
+// =============================================================================================
+// convz16: conv1 8->16 s2, conv2 16->16 and conv3 16->32 s2 (models/mvsnet.py:38-41) for 16-bit storage as
+// z-MARCHING kernels, the scheme of conv0z16 above with the standard operand mapping of convg16 (k = 4 taps x 8
+// channels per MFMA, 7 k-steps per 8-channel chunk, same panel): a 512-thread block owns an 8 x TX column of the
+// OUTPUT, a ring of input planes (all chunks) lives in LDS -- four planes for stride 1, five for stride 2, where two
+// new planes enter per output plane --, requested three steps ahead into rotating register sets, the whole panel in
+// registers, one block barrier per output plane, branch-free VMEM, 16-byte stores through a wave-private strip.
+// The tile kernels re-staged a 3-plane halo per one or two output planes and wrote 2-byte pieces.
+// =============================================================================================
+template <int CIN, int COUT, int S>
+struct ConvZ16 {
+    static constexpr int TY = 8, TX = (S == 1) ? 32 : 16;      // output column
+    static constexpr int NCH = CIN / 8, NT = COUT / 16;
+    static constexpr int MPW = (TY / 2) * (TX / 8) / 8;          // M-tiles (2 x 8 outputs) per wave: 2 / 1
+    static constexpr int HY = (TY - 1) * S + 3, HX = (TX - 1) * S + 3;
+    static constexpr int HXP = ((HX + 7) / 8 * 8) | 8;           // row pitch: odd multiple of 8 voxels (convg16's rule)
+    static constexpr int CHS = HY * HXP * 8;                     // 16-bit elements of one chunk of one plane
+    static constexpr int SLOT = NCH * CHS;
+    static constexpr int RING = (S == 1) ? 4 : 5;
+    static constexpr int THREADS = 512;
+    static constexpr int NPIECE = NCH * HY * HX;                 // 16-byte pieces of one plane
+    static constexpr int PPT = (NPIECE + THREADS - 1) / THREADS;
+    static constexpr int STRIP = 16 * 16 * MPW;                  // 16-bit elements: [M-tile][voxel 16][channel 16]
+    static_assert(MPW == 1 || MPW == 2, "one or two M-tiles per wave");
+    static_assert((RING * SLOT + 8 * STRIP * NT) * 2 <= 160 * 1024, "ring exceeds the CU's LDS");
+};
+
+template <int DT, int CIN, int COUT, int S>
+__global__ __launch_bounds__(512) void convz16_mfma_kernel(
+    const void* __restrict__ x,             // [CIN/8][Di][Hi][Wi][8] 16-bit
+    const unsigned short* __restrict__ bp,  // [NCH][NT][7][64][8] 16-bit (pack_convg16_weights)
+    const float* __restrict__ bias,         // [COUT]
+    void* __restrict__ y,                   // [COUT/8][Do][Ho][Wo][8] 16-bit
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ZC, int nbx, int nby) {
+    using G = ConvZ16<CIN, COUT, S>;
+    __shared__ __attribute__((aligned(16))) unsigned short ring[G::RING * G::SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short strips[8 * G::STRIP * G::NT];
+    const unsigned short* xs = static_cast<const unsigned short*>(x);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b;
+    {   // XCD k works through the k-th eighth of the (z chunk, row, column) sequence
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ox0 = bx * G::TX, oy0 = by * G::TY;
+    const int za = bz * ZC, zb = min(za + ZC, Do);
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
+    const size_t HW8 = (size_t)Hi * Wi * 8, Vin8 = (size_t)Di * HW8;
+
+    // staging: piece p = tid + i * THREADS -> (chunk, hy, hx)
+    size_t goff[G::PPT];
+    int loff[G::PPT];
+    unsigned okxy = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int p = tid + i * G::THREADS;
+        const int hx = p % G::HX, t = p / G::HX;
+        const int hy = t % G::HY, c = t / G::HY;
+        const int gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = p < G::NPIECE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        goff[i] = ok ? (size_t)c * Vin8 + ((size_t)gy * Wi + gx) * 8 : 0;
+        okxy |= ok ? (1u << i) : 0u;
+        loff[i] = p < G::NPIECE ? c * G::CHS + (hy * G::HXP + hx) * 8 : -1;
+    }
+    auto load_plane = [&](int gz, u32x4 (&st)[G::PPT]) {   // raw loads (plane clamped into the volume); masked when stored
+        const size_t zo = (size_t)min(max(gz, 0), Di - 1) * HW8;
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) st[i] = *reinterpret_cast<const u32x4*>(xs + goff[i] + zo);
+    };
+    auto slot_of = [&](int gz) { return ((gz + 1) % G::RING) * G::SLOT; };   // gz >= -1
+    auto store_plane = [&](int gz, const u32x4 (&st)[G::PPT]) {
+        unsigned short* slot = ring + slot_of(gz);
+        const bool zok = gz >= 0 && gz < Di;
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i)
+            if (loff[i] >= 0)
+                *reinterpret_cast<u32x4*>(slot + loff[i]) = (zok && ((okxy >> i) & 1u)) ? st[i] : (u32x4){0u, 0u, 0u, 0u};
+    };
+
+    // the whole panel in registers: breg[c][nt][ks]
+    u32x4 breg[G::NCH][G::NT][7];
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c)
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks)
+                breg[c][nt][ks] = reinterpret_cast<const u32x4*>(bp)[((c * G::NT + nt) * 7 + ks) * 64 + lane];
+
+    // A fragment: lane (r -> voxel (ry, rx) of the M-tile, g -> tap 4 ks + g)
+    const int r = lane & 15, g = lane >> 4;
+    int mt_off[G::MPW];   // M-tile origin inside a chunk plane; wave -> M-tiles MPW * wave ..
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = G::MPW * wave + i;
+        const int tx = t % (G::TX / 8), ty = t / (G::TX / 8);
+        mt_off[i] = ((S * (2 * ty + (r >> 3))) * G::HXP + S * (8 * tx + (r & 7))) * 8;
+    }
+    int kin[7], kzl[7];   // this lane's tap of k-step ks: offset inside a plane, plane kz
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int tap = min(4 * ks + g, 26);   // tap 27 is padding (zero weights): any valid address
+        kzl[ks] = tap / 9;
+        kin[ks] = (((tap / 3) % 3) * G::HXP + tap % 3) * 8;
+    }
+    const int n = lane & 15;
+    float bv[G::NT];
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) bv[nt] = bias[16 * nt + n];
+    unsigned short* strip = strips + wave * G::STRIP * G::NT;
+    // epilogue store role: lane -> (M-tile sm, voxel sv, 8-channel half sh) of each N-tile
+    const int sm = lane >> 5, sv = (lane >> 1) & 15, sh = lane & 1;
+    const bool s_have = sm < G::MPW;
+    const int st_t = G::MPW * wave + (s_have ? sm : 0);
+    const int sgy = oy0 + 2 * (st_t / (G::TX / 8)) + (sv >> 3), sgx = ox0 + 8 * (st_t % (G::TX / 8)) + (sv & 7);
+    const bool st_ok = s_have && sgy < Ho && sgx < Wo;
+    const size_t Vout8 = (size_t)Do * Ho * Wo * 8;
+    const unsigned st_off = (unsigned)(((size_t)sh * Vout8 + ((size_t)sgy * Wo + sgx) * 8) * 2);   // + 2 nt planes
+    const unsigned zstep_b = (unsigned)((size_t)Ho * Wo * 8 * 2), nt_b = (unsigned)(2 * Vout8 * 2);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, (short)0, (int)(unsigned)((COUT / 8) * Vout8 * 2), 0x00020000);
+
+    // prologue: input planes S za - 1 .. S za + 1 into the ring; the planes of steps za and za + 1 in flight
+    u32x4 w[3][S][G::PPT];   // [register set][plane of the step][piece]
+    {
+        u32x4 t0[G::PPT], t1[G::PPT], t2[G::PPT];
+        load_plane(S * za - 1, t0);
+        load_plane(S * za, t1);
+        load_plane(S * za + 1, t2);
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_plane(S * za + 2 + q, w[0][q]);
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_plane(S * (za + 1) + 2 + q, w[1][q]);
+        store_plane(S * za - 1, t0);
+        store_plane(S * za, t1);
+        store_plane(S * za + 1, t2);
+    }
+    __syncthreads();
+
+    // one output plane zo: set `nx` receives the planes step zo + 2 will write, set `cur` (requested two steps ago) goes
+    // into the ring at the end, into the slots of planes no step reads any more
+    auto step = [&](int zo, u32x4 (&cur)[S][G::PPT], u32x4 (&nx)[S][G::PPT]) {
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_plane(S * (zo + 2) + 2 + q, nx[q]);
+        int sb[3];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) sb[kz] = slot_of(S * zo - 1 + kz);
+        f32x4 acc[G::MPW][G::NT];
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i)
+#pragma unroll
+            for (int nt = 0; nt < G::NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int sl = (kzl[ks] == 0 ? sb[0] : kzl[ks] == 1 ? sb[1] : sb[2]) + kin[ks];
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < G::MPW; ++i) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(ring + sl + c * G::CHS + mt_off[i]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[i][nt] = mfma16<DT>(a, breg[c][nt][ks], acc[i][nt]);
+                }
+        }
+        // epilogue: element e of acc[i][nt] = voxel m = 4 g + e of M-tile i, channel 16 nt + n -> strip[nt][i][m][n]
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(acc[i][nt][e] + bv[nt], 0.0f);
+                    unsigned short bits;
+                    if (DT == MVS_F16) { const _Float16 hv = (_Float16)v; bits = __builtin_bit_cast(unsigned short, hv); }
+                    else { const __bf16 hv = (__bf16)v; bits = __builtin_bit_cast(unsigned short, hv); }
+                    strip[nt * G::STRIP + (i * 16 + 4 * g + e) * 16 + n] = bits;
+                }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt) {
+            const u16x8 o = *reinterpret_cast<const u16x8*>(strip + nt * G::STRIP + ((s_have ? sm : 0) * 16 + sv) * 16 + sh * 8);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs,
+                                                   (int)((st_ok && zo < zb) ? st_off + (unsigned)nt * nt_b + (unsigned)zo * zstep_b : 0xFFFFFFF0u), 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < S; ++q) store_plane(S * zo + 2 + q, cur[q]);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int zo = za; zo < zb; zo += 3) {   // up to two surplus steps at the end of a chunk: their stores are dropped
+        step(zo, w[0], w[2]);
+        step(zo + 1, w[1], w[0]);
+        step(zo + 2, w[2], w[1]);
+    }
+}
+
+template <int DT, int CIN, int COUT, int S>
+static int run_convz16(const void* x, void* y, const unsigned short* bp, const float* bias, int Di, int Hi, int Wi,
+                       int Do, int Ho, int Wo, int cus, hipStream_t s) {
+    using G = ConvZ16<CIN, COUT, S>;
+    const int nbx = (Wo + G::TX - 1) / G::TX, nby = (Ho + G::TY - 1) / G::TY, ncol = nbx * nby;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int nz = 1; nz <= (Do + 3) / 4; ++nz) {   // z chunks of >= 4 output planes: best fill of the last round
+        const int zc = (Do + nz - 1) / nz, nzc = (Do + zc - 1) / zc;
+        const long nb = (long)ncol * nzc;
+        const double eff = (double)nb / (double)(((nb + cus - 1) / cus) * cus) * zc / (zc + 2.5);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+    }
+    const int ZC = (Do + best - 1) / best, nzc = (Do + ZC - 1) / ZC;
+    convz16_mfma_kernel<DT, CIN, COUT, S><<<ncol * nzc, G::THREADS, 0, s>>>(x, bp, bias, y, Di, Hi, Wi, Do, Ho, Wo, ZC, nbx, nby);
+    return check_hip(hipGetLastError(), "convz16_mfma launch");
+}
+
+// layers 1..3 through the z-marching kernel when their columns fill the chip (MVS_CONVZ16=0/1 = never / always)
+template <int DT>
+static int try_convz16(int layer, const void* x, void* y, const unsigned short* bp, const float* bias, int Di, int Hi,
+                       int Wi, hipStream_t s, bool* taken) {
+    *taken = false;
+    static const int zm = [] {
+        const char* e = getenv("MVS_CONVZ16");
+        return e ? atoi(e) : -1;
+    }();
+    if (zm == 0 || layer < 1 || layer > 3) return MVS_OK;
+    const int S = layer == 2 ? 1 : 2, cout = layer == 3 ? 32 : 16;
+    const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const int tx = S == 1 ? 32 : 16;
+    const long ncol = (long)((Wo + tx - 1) / tx) * ((Ho + 7) / 8);
+    if ((size_t)Do * Ho * Wo * cout * 2 >= ((size_t)1 << 32) - 64 || Do < 4) return MVS_OK;
+    // enough columns x 8-plane chunks to fill the chip (cfg5's conv3 -- 12 columns of 48 planes -- measured 0.016 vs
+    // 0.012 ms for the tile kernel: short chunks pay the two-step prologue too often)
+    if (zm != 1 && ncol * (Do / 8) * 4 < (long)cus * 3) return MVS_OK;
+    *taken = true;
+    switch (layer) {
+        case 1: return run_convz16<DT, 8, 16, 2>(x, y, bp, bias, Di, Hi, Wi, Do, Ho, Wo, cus, s);
+        case 2: return run_convz16<DT, 16, 16, 1>(x, y, bp, bias, Di, Hi, Wi, Do, Ho, Wo, cus, s);
+        default: return run_convz16<DT, 16, 32, 2>(x, y, bp, bias, Di, Hi, Wi, Do, Ho, Wo, cus, s);
+    }
+}
+
 // wfold [27][32][8] -> bp [4][9][64][8] (16-bit): k = (g = kx', j = ci of the chunk), n = (jj, co)
 void pack_conv0p16_weights(const float* wfold, int dt, unsigned short* bp) {
     for (int c = 0; c < 4; ++c)
@@ -774,6 +1022,11 @@ static int launch_layer16_dt(int layer, const void* x, const void* skip, void* y
         const int nb = ((Wi + TX - 1) / TX) * ((Hi + TY - 1) / TY) * ((Di + TZ - 1) / TZ);
         conv0p16_mfma_kernel<DT><<<nb, 256, 0, s>>>(x, bp, bias, y, Di, Hi, Wi);
         return check_hip(hipGetLastError(), "conv0p16_mfma launch");
+    }
+    if (layer <= 3) {
+        bool taken = false;
+        const int st = try_convz16<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s, &taken);
+        if (taken) return st;
     }
     if (layer <= 6) return launch_convg16_dt<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s);
     switch (layer) {

@@ -372,6 +372,11 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_CONV0Z16": "1"}, ("24", "24", "40", "f16", "bf16")),
     ({"MVS_CONV0Z16": "1"}, ("16", "16", "32", "bf16")),
     ({"MVS_CONV0Z16": "0"}, ("16", "16", "32", "f16")),
+    # z-marching 16-bit conv1 / conv2 / conv3 (conv3d_mfma16.hip convz16: default once their columns fill the chip),
+    # and the tile kernels they replace at full size
+    ({"MVS_CONVZ16": "1"}, ("24", "24", "40", "f16", "bf16")),
+    ({"MVS_CONVZ16": "1"}, ("16", "16", "32", "bf16")),
+    ({"MVS_CONVZ16": "0", "MVS_CONV0Z16": "0"}, ("16", "16", "32", "bf16")),
     # z-marching fp32 conv1 (conv3d_mfma.hip: default once its columns fill the chip): several z chunks with
     # surplus steps, ragged y / x tiles (h/2 = 12 rows for 8-row tiles, w/2 = 20 for 16-column tiles)
     ({"MVS_CONV1Z": "1"}, ("24", "24", "40", "f32")),
