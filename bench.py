@@ -85,6 +85,51 @@ def stage_costs(N, D, h, w, es=4):
     return costs
 
 
+def live_traffic(kernel_substr, what, reps=3, timeout=150):
+    """HBM bytes per launch of one kernel, measured NOW: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE;
+    each with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over `tools/prof_stage.py <what> <reps>` -- the
+    same kernel on the same cfg2 inputs -- run as child processes of this one.  gfx950 correction: FETCH_SIZE under-
+    reports wide streaming reads by 2x.  Returns None when rocprofv3 is missing, fails or times out."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out_dir = os.path.join(td, ctr)
+                cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "--",
+                       sys.executable, os.path.join(REPO, "tools", "prof_stage.py"), what, str(reps)]
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                        stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=timeout)
+                except subprocess.TimeoutExpired:
+                    os.killpg(proc.pid, signal.SIGKILL)     # exactly the process group started above
+                    proc.wait()
+                    return None
+                if rc != 0:
+                    return None
+                vals = []
+                for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                    with open(path) as f:
+                        for row in csv.DictReader(f):
+                            if row.get("Counter_Name") == ctr and kernel_substr in (row.get("Kernel_Name") or ""):
+                                vals.append(float(row["Counter_Value"]))
+                if not vals:
+                    return None
+                got[ctr] = sum(vals) / len(vals)
+    except (OSError, ValueError, KeyError):
+        return None
+    return int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +144,9 @@ def parse_args(argv=None):
                          "--warmup steps, reported as `first_pass`) and the pass reported as `value`; 0 = one pass only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (from images) figure")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the committed profiles/rNN_traffic.json instead of measuring it now "
+                         "(two rocprofv3 --pmc child runs of ~10 s each, after everything else)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams to round-robin independent maps over (each has its own workspace); two maps "
                          "in flight fill the launch gaps and the tails of the small U-Net layers (+6 %% over 1)")
@@ -393,8 +441,8 @@ def main(argv=None):
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": c["bytes"]}
 
-    # HBM traffic of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction; profiles/r01_traffic.json)
+    # HBM traffic of the dominant kernel: the committed PMC profile (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # passes, gfx950 FETCH x2 correction) first; replaced by a live measurement at the very end (below) when possible
     if roofline is not None and args.config == "cfg2":
         try:
             import glob
@@ -402,7 +450,7 @@ def main(argv=None):
             with open(newest) as f:
                 prof = json.load(f)["kernels"]
             want = {"conv0": "conv0_w43_mfma_kernel<0>" if wino == "4" else "conv0_4x4_mfma_kernel<0>",
-                    "warp_variance": "warp_variance_tc2_kernel<0, 0, 4, 4, 0>"}.get(roofline["kernel"], "?")
+                    "warp_variance": "warp_variance_tc2_kernel<0, 0, 4, 4, 0, 1>"}.get(roofline["kernel"], "?")
             ent = next((v for k, v in prof.items() if k.endswith(want)), None)
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
@@ -471,6 +519,20 @@ def main(argv=None):
             torch.cuda.synchronize()
             end_to_end[mode] = round(K / (time.perf_counter() - te), 2)
         end_to_end["streams"] = S
+
+    # live PMC measurement of the dominant kernel's HBM traffic (rank 0 of a one-GPU cfg2 run; after every timing)
+    if (rank == 0 and world == 1 and roofline is not None and args.config == "cfg2" and storage == "f32"
+            and not args.no_live_traffic and roofline["kernel"] in ("conv0", "warp_variance")):
+        torch.cuda.synchronize()
+        sub = {"conv0": "conv0_w43_mfma_kernel" if wino == "4" else "conv0_4x4_mfma_kernel",
+               "warp_variance": "warp_variance_tc2_kernel"}[roofline["kernel"]]
+        t_live = time.perf_counter()
+        live = live_traffic(sub, "conv0" if roofline["kernel"] == "conv0" else "warp")
+        if live:
+            roofline["traffic"] = live
+            roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child "
+                                          "passes, --kernel-trace only) over tools/prof_stage.py, per launch; FETCH x2 gfx950 "
+                                          f"correction; {time.perf_counter() - t_live:.0f} s")
 
     if rank == 0:
         line = {

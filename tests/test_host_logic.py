@@ -448,3 +448,10 @@ def test_rank_cpus_follow_the_gpu_numa_node(tmp_path):
     assert sharding.visible_gpu_order(8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1,0"}) == [5, 4]
     assert sharding.visible_gpu_order(4, {"HIP_VISIBLE_DEVICES": "GPU-abc"}) == [0, 1, 2, 3]
     assert sharding.visible_gpu_order(2, {"CUDA_VISIBLE_DEVICES": "0,5"}) == [0, 1]     # out of range: ignored
+
+
+def test_bench_live_traffic_degrades_to_none_without_a_gpu():
+    """bench.py measures roofline.traffic with rocprofv3 child passes; where that cannot work (no GPU here, or no
+    rocprofv3) it must return None quickly -- the line then carries the committed profile's figure."""
+    bench = _bench()
+    assert bench.live_traffic("conv0_w43_mfma_kernel", "conv0", reps=1, timeout=60) is None
