@@ -450,8 +450,31 @@ def test_rank_cpus_follow_the_gpu_numa_node(tmp_path):
     assert sharding.visible_gpu_order(2, {"CUDA_VISIBLE_DEVICES": "0,5"}) == [0, 1]     # out of range: ignored
 
 
-def test_bench_live_traffic_degrades_to_none_without_a_gpu():
-    """bench.py measures roofline.traffic with rocprofv3 child passes; where that cannot work (no GPU here, or no
-    rocprofv3) it must return None quickly -- the line then carries the committed profile's figure."""
+def test_bench_live_traffic_parses_pmc_passes_and_degrades_to_none(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic with two rocprofv3 child passes; a stand-in `rocprofv3` on PATH checks the
+    command line it is given (one counter per pass, --kernel-trace only, the program itself after `--`) and the
+    parsing (per-launch average of the named kernel, FETCH x2 + WRITE, KiB units); a failing one gives None."""
+    import stat
     bench = _bench()
-    assert bench.live_traffic("conv0_w43_mfma_kernel", "conv0", reps=1, timeout=60) is None
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+assert a[0] == "--pmc" and a[2] == "--kernel-trace" and "--sys-trace" not in a and "python" in os.path.basename(a[a.index("--") + 1])
+ctr, out = a[1], a[a.index("-d") + 1]
+if os.environ.get("FAKE_FAIL"):
+    sys.exit(3)
+os.makedirs(os.path.join(out, "host"), exist_ok=True)
+val = {"FETCH_SIZE": [1000.0, 3000.0], "WRITE_SIZE": [500.0, 500.0]}[ctr]
+with open(os.path.join(out, "host", "1_counter_collection.csv"), "w") as f:
+    f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+    for v in val:
+        f.write(f'"void mvs::conv0_w43_mfma_kernel<0>(x)",{ctr},{v}\n')
+    f.write(f'"void mvs::other_kernel(x)",{ctr},777777\n')
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    assert bench.live_traffic("conv0_w43_mfma_kernel", "conv0", reps=1, timeout=30) == int((2 * 2000.0 + 500.0) * 1024)
+    assert bench.live_traffic("no_such_kernel", "conv0", reps=1, timeout=30) is None
+    monkeypatch.setenv("FAKE_FAIL", "1")
+    assert bench.live_traffic("conv0_w43_mfma_kernel", "conv0", reps=1, timeout=30) is None
