@@ -467,10 +467,10 @@ if os.environ.get("FAKE_FAIL"):
 os.makedirs(os.path.join(out, "host"), exist_ok=True)
 val = {"FETCH_SIZE": [1000.0, 3000.0], "WRITE_SIZE": [500.0, 500.0]}[ctr]
 with open(os.path.join(out, "host", "1_counter_collection.csv"), "w") as f:
-    f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+    f.write("Kernel_Name,Counter_Name,Counter_Value\\n")
     for v in val:
-        f.write(f'"void mvs::conv0_w43_mfma_kernel<0>(x)",{ctr},{v}\n')
-    f.write(f'"void mvs::other_kernel(x)",{ctr},777777\n')
+        f.write(f'"void mvs::conv0_w43_mfma_kernel<0>(x)",{ctr},{v}\\n')
+    f.write(f'"void mvs::other_kernel(x)",{ctr},777777\\n')
 """)
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
