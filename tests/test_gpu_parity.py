@@ -332,6 +332,33 @@ def test_optin_kernel_variants(env):
 
 
 @pytest.mark.parametrize("storage", ["f16", "bf16"])
+def test_16bit_storage_fp32_feature_copy_variant(storage):
+    """MVS_FEAT16=0: the 16-bit modes gather from the fp32 feature copy (features not narrowed); against the oracle
+    with the usual rounding points -- the un-rounded features move the depth far less than the bound."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_fixture, load_weights, rel_l1\n"
+        "from oracle import oracle as orc\n"
+        "from scene_3dreconstruction_mvsnet_amd import _lib\n"
+        "fx = load_fixture('n5yaw'); sd = orc.costreg_state(load_weights()); st = %r\n"
+        "f, p, d = fx['features'][0], fx['proj_matrices'][0], fx['depth_values'][0]\n"
+        "dev = 'cuda:0'; cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)\n"
+        "N, C, h, w = f.shape; dt = _lib.dtype_code(st)\n"
+        "ws = _lib.alloc_workspace(N, C, d.shape[0], h, w, dev, dt)\n"
+        "depth = torch.empty((h, w), device=dev); conf = torch.empty_like(depth)\n"
+        "_lib.depth_infer(cu(f), cu(p), cu(d), _lib.pack_weights(sd).to(dev), ws, depth, conf, dtype=dt)\n"
+        "want, _ = orc.depth_infer(f, p, d, sd, storage=st)\n"
+        "r = rel_l1(depth.cpu().numpy(), want); print(r); sys.exit(0 if r < (2e-4 if st == 'f16' else 1e-3) else 1)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), storage)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVS_FEAT16="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
 def test_16bit_storage_fp32_arithmetic_variant(storage):
     """MVS_MFMA16=0: fp32 MFMA on the narrowed operands, against the oracle that rounds storage only."""
     import os
