@@ -85,11 +85,111 @@ def stage_costs(N, D, h, w, es=4):
     return costs
 
 
-def live_traffic(kernel_substr, what, reps=3, timeout=150):
+def executed_costs(costs, storage, N, D, h, w, env=None):
+    """What THIS BUILD executes / moves per stage, next to the algorithmic d3 figures of `stage_costs`:
+    * fp32 storage: conv0 runs Winograd F(4,3) along z (6 transformed planes x 9 taps per 4 output planes = 1/2 of the
+      27 multiply-adds per output), conv2 / conv4 F(2,3) along z on the 16x16x4 MFMA (4 planes x 10 tap slots per 2
+      output planes = 20/27) -- unless MVS_CONV0_WINO=0 / MVS_CONV_WINO=0 (csrc/conv3d_direct.hip:460-480);
+    * 16-bit storage: the logits stay fp32 (conv11+prob writes, softargmin reads 4 bytes per voxel).
+    A roofline fraction computed from these never exceeds 1."""
+    env = os.environ if env is None else env
+    ex = {k: dict(v) for k, v in costs.items()}
+    V0 = D * h * w
+    if storage == "f32":
+        if env.get("MVS_FORCE_DIRECT") != "1":
+            if env.get("MVS_CONV0_WINO") != "0" and D % 4 == 0 and V0 * 32 < (1 << 31):
+                ex["conv0"]["flops"] = costs["conv0"]["flops"] * 0.5
+            if env.get("MVS_CONV_WINO") != "0":
+                for n in ("conv2", "conv4"):
+                    ex[n]["flops"] = costs[n]["flops"] * 20.0 / 27.0
+    else:
+        for n in ("prob", "conv11_prob", "softargmin"):
+            ex[n]["bytes"] = costs[n]["bytes"] + V0 * 2
+    return ex
+
+
+def stage_entry(ms, c_alg, c_ex, mfma_peak):
+    """One `stages` entry: measured ms, the rates, and two roofline fractions -- `frac` from what the kernel really
+    executes / moves (<= 1 by construction), `frac_algorithmic` from SURVEY d3's algorithmic bytes / FLOPs (a Winograd
+    kernel can exceed 1 there: it issues fewer multiply-adds than the algorithm counts)."""
+    ent = {"ms": round(ms, 4)}
+    if not c_alg or ms <= 0:
+        return ent
+    ent["GBps"] = round(c_alg["bytes"] / ms / 1e6, 1)
+    if c_alg["flops"]:
+        ent["TFLOPs"] = round(c_alg["flops"] / ms / 1e9, 2)
+    t_hbm, t_mfma = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e6), c_ex["flops"] / (mfma_peak * 1e9)
+    ent["bound"] = "mfma" if t_mfma > t_hbm else "hbm"
+    ent["frac"] = round(max(t_hbm, t_mfma) / ms, 3)
+    alg_ms = max(c_alg["bytes"] / (HBM_PEAK_GBPS * 1e6), c_alg["flops"] / (mfma_peak * 1e9))
+    ent["frac_algorithmic"] = round(alg_ms / ms, 3)
+    return ent
+
+
+def roofline_entry(dom, ms, c_alg, c_ex, mfma_peak):
+    """The `roofline` object of the dominant kernel.  `achieved` / `frac` are the EXECUTED rate (what the matrix pipe
+    or HBM really did per second); the algorithmic rate of SURVEY d3 travels as `achieved_algorithmic` /
+    `algorithmic_ratio` (not a fraction of peak: > 1 is possible for a Winograd kernel)."""
+    t_hbm = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e9)
+    t_mfma = c_ex["flops"] / (mfma_peak * 1e12)
+    if t_mfma > t_hbm:
+        ach, alg = c_ex["flops"] / ms / 1e9, c_alg["flops"] / ms / 1e9
+        r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": mfma_peak, "unit": "TFLOP/s",
+             "frac": round(ach / mfma_peak, 4), "traffic": None, "avg_launch_ms": ms,
+             "achieved_algorithmic": round(alg, 3), "algorithmic_ratio": round(alg / mfma_peak, 4),
+             "algorithmic_flops": c_alg["flops"], "executed_flops": c_ex["flops"],
+             "algorithmic_bytes": c_alg["bytes"]}
+        if c_ex["flops"] != c_alg["flops"]:
+            r["note"] = (f"{dom} runs a Winograd transform along z: it issues {c_ex['flops'] / c_alg['flops']:.3f} of "
+                         "the algorithmic multiply-adds; `frac` = executed MFMA flops / time / peak")
+    else:
+        ach, alg = c_ex["bytes"] / ms / 1e6, c_alg["bytes"] / ms / 1e6
+        r = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_ms": ms,
+             "achieved_algorithmic": round(alg, 1), "algorithmic_ratio": round(alg / HBM_PEAK_GBPS, 4),
+             "algorithmic_bytes": c_alg["bytes"], "executed_bytes": c_ex["bytes"]}
+    return r
+
+
+# stage -> (kernel-name substring in the rocprofv3 trace, tools/prof_stage.py selector, FETCH_SIZE factor).
+# gfx950: FETCH_SIZE under-reports wide coalesced 16 B/lane streaming reads by 2x (MI355X_MICROARCH.md, HBM section):
+# valid for the staging loads of the conv kernels, NOT for the scattered tap gathers of the warp kernel (x1).
+TRAFFIC_KERNELS = {
+    "conv0": ("conv0", "conv0", 2.0),
+    "warp_variance": ("warp_variance_tc2_kernel", "warp", 1.0),
+    "conv11_prob": ("conv11_prob", "all", 2.0),
+}
+
+
+def committed_traffic(stage, config):
+    """HBM bytes per launch of `stage`'s kernel from the newest committed PMC profile of that config
+    (profiles/rNN_traffic.json = cfg2, profiles/rNN_traffic_<cfg>.json otherwise) -> (bytes, source) or (None, None)."""
+    import glob
+    if stage not in TRAFFIC_KERNELS:
+        return None, None
+    sub, _, factor = TRAFFIC_KERNELS[stage]
+    pat = "r*_traffic.json" if config == "cfg2" else f"r*_traffic_{config}.json"
+    try:
+        newest = sorted(glob.glob(os.path.join(REPO, "profiles", pat)))[-1]
+        with open(newest) as f:
+            prof = json.load(f)["kernels"]
+        ents = [v for k, v in prof.items() if sub in k and "FETCH_SIZE_KB_avg" in v]
+        if not ents:
+            return None, None
+        ent = max(ents, key=lambda v: v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"])
+        val = int((factor * ent["FETCH_SIZE_KB_avg"] + ent["WRITE_SIZE_KB_avg"]) * 1024)
+        return val, (f"profiles/{os.path.basename(newest)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
+                     f"kernel, per launch; FETCH x{factor:g} -- the gfx950 correction of this kernel's load pattern)")
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+def live_traffic(kernel_substr, what, reps=3, timeout=150, cfg="cfg2", storage="f32", fetch_factor=2.0):
     """HBM bytes per launch of one kernel, measured NOW: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE;
-    each with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over `tools/prof_stage.py <what> <reps>` -- the
-    same kernel on the same cfg2 inputs -- run as child processes of this one.  gfx950 correction: FETCH_SIZE under-
-    reports wide streaming reads by 2x.  Returns None when rocprofv3 is missing, fails or times out."""
+    each with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over `tools/prof_stage.py <what> <reps> <cfg>
+    <dtype>` -- the same kernel on the same inputs -- run as child processes of this one.  `fetch_factor`: the gfx950
+    FETCH_SIZE correction for that kernel's load pattern (TRAFFIC_KERNELS).  Returns None when rocprofv3 is missing,
+    fails or times out."""
     import csv
     import glob
     import shutil
@@ -105,7 +205,7 @@ def live_traffic(kernel_substr, what, reps=3, timeout=150):
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 out_dir = os.path.join(td, ctr)
                 cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "--",
-                       sys.executable, os.path.join(REPO, "tools", "prof_stage.py"), what, str(reps)]
+                       sys.executable, os.path.join(REPO, "tools", "prof_stage.py"), what, str(reps), cfg, storage]
                 proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                         stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
@@ -127,7 +227,7 @@ def live_traffic(kernel_substr, what, reps=3, timeout=150):
                 got[ctr] = sum(vals) / len(vals)
     except (OSError, ValueError, KeyError):
         return None
-    return int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+    return int((fetch_factor * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
 
 
 def parse_args(argv=None):
@@ -144,6 +244,9 @@ def parse_args(argv=None):
                          "--warmup steps, reported as `first_pass`) and the pass reported as `value`; 0 = one pass only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (from images) figure")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the path-only runs of BASELINE configs 3 (bf16 1600x1184x256) and 5 (fp16 N=4) that the "
+                         "default cfg2 one-GPU run adds as `other_configs`")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="take roofline.traffic from the committed profiles/rNN_traffic.json instead of measuring it now "
                          "(two rocprofv3 --pmc child runs of ~10 s each, after everything else)")
@@ -190,45 +293,23 @@ def self_launch(args, argv) -> int:
     return proc.returncode if proc.returncode or lines else 1
 
 
-def main(argv=None):
-    argv = sys.argv[1:] if argv is None else argv
-    args = parse_args(argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args, argv))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+class Ctx:
+    """Process-wide state shared by the per-config measurements."""
+    pass
 
-    global torch, dist, _lib, sharding, synthetic
-    import torch
-    import torch.distributed as dist
-    from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic
-    # one process per GPU: keep this rank's host threads on the cores next to its GPU (before any GPU call)
-    pinned = sharding.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    # MVS_BENCH_REHEARSAL=1: run every rank on cuda:0 with the gloo backend -- a way to exercise
-    # the N>1 code path on a one-GPU box (numbers are meaningless; the driver never sets it)
-    rehearsal = os.environ.get("MVS_BENCH_REHEARSAL") == "1"
-    dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = synthetic.CONFIGS[args.config]
+def measure(ctx, config, storage, K, Wm, prewarm_ms, S, KS, staged_timed=False):
+    """Time the hot path on one BASELINE config: W warm-up steps, the K steps right after them (`first`), the same K
+    steps again after `prewarm_ms` of the same workload (`sustained`), then KS maps through the per-stage C-ABI calls
+    with a HIP event after each kernel.  Returns a dict; every rank takes part (barriers + gather inside the timed
+    region when world > 1)."""
+    torch, dist, _lib, sharding, synthetic = ctx.torch, ctx.dist, ctx._lib, ctx.sharding, ctx.synthetic
+    dev, rank, world, rehearsal = ctx.dev, ctx.rank, ctx.world, ctx.rehearsal
+    cfg = synthetic.CONFIGS[config]
     N, D, h, w = cfg["nviews"], cfg["D"], cfg["H"] // 4, cfg["W"] // 4
-    K, Wm = args.steps, args.warmup
-    storage = args.dtype or {"cfg3": "bf16", "cfg5": "f16"}.get(args.config, "f32")
     dt = _lib.dtype_code(storage)
     es = 4 if storage == "f32" else 2
-    _lib.load()
+    lib = _lib.load()
 
     # ---- synthetic problem (per-rank seed: every rank owns different ref views) -------------
     feats_np = synthetic.random_features(N, 32, h, w, seed=rank)
@@ -242,7 +323,6 @@ def main(argv=None):
     # fraction of the (pixel, depth, source view) sampling points that land inside the source image
     # (out-of-image taps are cheaper, so the figure travels with every timing)
     in_image_frac = round(synthetic.in_image_fraction(proj_np, dv_np, h, w), 4)
-    S = max(1, args.streams)
     wss = [_lib.alloc_workspace(N, 32, D, h, w, dev, dt) for _ in range(S)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     out = torch.zeros((K, 2, h, w), dtype=torch.float32, device=dev)  # depth, conf per step
@@ -255,19 +335,15 @@ def main(argv=None):
         layer_names = layer_names[:9] + ["conv11_prob"]
     stage_names = ["relative_proj", "warp_variance"] + layer_names + ["softargmin"]
     n_ev = len(stage_names) + 1
-    KS = max(0, args.staged_steps)      # maps of the per-kernel event pass after the timed region
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(max(K, KS))]
 
     # Pre-allocated per-stream buffers and pre-bound C calls keep the host ahead of the GPU in the
     # staged mode (no torch allocations or shape logic inside the timed loop).
-    lib = _lib.load()
-    V0 = D * h * w
-
     def lvl(c, l):
         return torch.empty((c // 8, D >> l, h >> l, w >> l, 8), dtype=_lib.TORCH_DTYPES[dt], device=dev)
 
     bufs = []
-    for si in range(S):
+    for si in range(S if staged_timed else 1):
         bufs.append(dict(rt=torch.empty((max(N - 1, 1), 12), dtype=torch.float32, device=dev),
                          var=lvl(32, 0),
                          act=[lvl(8, 0), lvl(16, 1), lvl(16, 1), lvl(32, 2), lvl(32, 2), lvl(64, 3),
@@ -276,8 +352,8 @@ def main(argv=None):
     skips = {7: 4, 8: 2, 9: 0}
 
     def step_staged(k, ev=None):
-        si = k % S
-        ws, B = wss[si], bufs[si]
+        si = k % len(bufs)
+        ws, B = wss[k % S], bufs[si]
         st = _lib._stream(dev)
         rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
         rec(0)
@@ -315,7 +391,7 @@ def main(argv=None):
 
     # Timed steps: one mvs_depth_infer call per map (what the drop-in's forward enqueues), maps
     # round-robin over the S streams (each stream has its own workspace).
-    step_one = step_staged if args.staged_timed else step_fused
+    step_one = step_staged if staged_timed else step_fused
 
     def step(k, ev=None):
         if S == 1:
@@ -373,7 +449,6 @@ def main(argv=None):
     # of the same workload, untimed -- the sustained rate the metric asks for.  Both are in the JSON line.
     first_elapsed = timed_pass()
     elapsed = first_elapsed
-    prewarm_ms = max(0, args.prewarm_ms)
     effective_warmup = Wm      # untimed steps in front of the pass reported as `value`
     if prewarm_ms:
         tp = time.perf_counter()
@@ -385,83 +460,141 @@ def main(argv=None):
             torch.cuda.synchronize()
         elapsed = timed_pass()
 
-    maps_per_s = world * K / elapsed
-    ms_per_step = elapsed / K * 1e3
-
     # ---- per-kernel durations: the same kernels on the same inputs through the per-stage C-ABI
     # calls, a HIP event (on the launch stream) after each, one stream, right after the timed region
     costs = stage_costs(N, D, h, w, es)
+    ex_costs = executed_costs(costs, storage, N, D, h, w)
     mfma_peak = mfma_peak_tflops(storage, os.environ.get("MVS_MFMA16") != "0")
     stages = {}
-    staged_steps = list(range(KS))
-    if staged_steps:
+    if KS:
         step_staged(0)
         torch.cuda.synchronize()
-        for k in staged_steps:
+        for k in range(KS):
             step_staged(k % K, events[k])
         torch.cuda.synchronize()
         for si, name in enumerate(stage_names):
-            ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in staged_steps]))
-            ent = {"ms": round(ms, 4)}
-            c = costs.get(name)
-            if c and ms > 0:
-                ent["GBps"] = round(c["bytes"] / ms / 1e6, 1)
-                if c["flops"]:
-                    ent["TFLOPs"] = round(c["flops"] / ms / 1e9, 2)
-                # fraction of this stage's own roofline: max(HBM time, MFMA time at the arithmetic dtype's peak) / measured
-                floor_ms = max(c["bytes"] / (HBM_PEAK_GBPS * 1e6), c["flops"] / (mfma_peak * 1e9))
-                ent["bound"] = "mfma" if c["flops"] / (mfma_peak * 1e9) > c["bytes"] / (HBM_PEAK_GBPS * 1e6) else "hbm"
-                ent["frac"] = round(floor_ms / ms, 3)
-            stages[name] = ent
+            ms = float(np.mean([events[k][si].elapsed_time(events[k][si + 1]) for k in range(KS)]))
+            stages[name] = stage_entry(ms, costs.get(name), ex_costs.get(name), mfma_peak)
     roofline = None
-    # which conv0 kernel the library picks (csrc/conv3d_direct.hip): F(4,3) unless told otherwise
-    wino = "0" if (os.environ.get("MVS_CONV0_WINO") == "0" or D % 4) else "4"
     if stages:
         dom = max((n for n in stages if n in costs), key=lambda n: stages[n]["ms"])
-        c, ms = costs[dom], stages[dom]["ms"]
-        t_hbm = c["bytes"] / (HBM_PEAK_GBPS * 1e9)
-        t_mfma = c["flops"] / (mfma_peak * 1e12)
-        if t_mfma > t_hbm:
-            ach = c["flops"] / ms / 1e9
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3),
-                        "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": round(ach / mfma_peak, 4), "traffic": None,
-                        "avg_launch_ms": ms, "algorithmic_flops": c["flops"],
-                        "algorithmic_bytes": c["bytes"]}
-            if dom == "conv0" and storage == "f32" and wino == "4":
-                num, den, form = 1, 2, "F(4,3)"
-                roofline["note"] = (f"conv0 runs Winograd {form} along z on the fp32 4x4x1 MFMA: it issues {num}/{den} "
-                                    "of the algorithmic multiply-adds; `achieved` is the ALGORITHMIC flops / time as "
-                                    f"SURVEY 8 d3 defines it (it can exceed the MFMA peak), the executed-MFMA rate is "
-                                    f"{num}/{den} of that")
-                roofline["executed_flops"] = c["flops"] * num // den
-        else:
-            ach = c["bytes"] / ms / 1e6
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                        "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": c["bytes"]}
+        roofline = roofline_entry(dom, stages[dom]["ms"], costs[dom], ex_costs[dom], mfma_peak)
+        # HBM traffic of the dominant kernel: the committed PMC profile of this config (separate rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes); main() replaces it by a live measurement at the very end when it can
+        roofline["traffic"], src = committed_traffic(dom, config)
+        if src:
+            roofline["traffic_source"] = src
 
-    # HBM traffic of the dominant kernel: the committed PMC profile (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # passes, gfx950 FETCH x2 correction) first; replaced by a live measurement at the very end (below) when possible
-    if roofline is not None and args.config == "cfg2":
-        try:
-            import glob
-            newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]
-            with open(newest) as f:
-                prof = json.load(f)["kernels"]
-            want = {"conv0": "conv0_w43_mfma_kernel<0>" if wino == "4" else "conv0_4x4_mfma_kernel<0>",
-                    "warp_variance": "warp_variance_tc2_kernel<0, 0, 4, 4, 0, 1>"}.get(roofline["kernel"], "?")
-            ent = next((v for k, v in prof.items() if k.endswith(want)), None)
-            if ent:
-                roofline["traffic"] = ent["hbm_bytes_fetch_x2"]
-                roofline["traffic_source"] = (f"profiles/{os.path.basename(newest)} (rocprofv3 --pmc FETCH_SIZE / "
-                                              "WRITE_SIZE passes of the same kernels, per launch; FETCH x2 gfx950 correction)")
-        except (OSError, KeyError, ValueError):
-            pass
-
-    # whole-path totals follow SURVEY.md §8 d3 (layer-by-layer, no fusion credited), independent of
-    # which kernels ran
+    # whole-path totals follow SURVEY.md §8 d3 (layer-by-layer, no fusion credited), independent of which kernels
+    # ran; the executed floor prices what this build's kernels really issue / move (fused tail counted once)
     path_bytes, path_flops, stagewise_floor_s = path_totals(costs, mfma_peak)
+    ran = [n for n in stage_names if n in ex_costs]
+    executed_floor_s = sum(max(ex_costs[n]["bytes"] / (HBM_PEAK_GBPS * 1e9), ex_costs[n]["flops"] / (mfma_peak * 1e12))
+                           for n in ran)
+    res = dict(config=config, storage=storage, N=N, D=D, h=h, w=w, H=cfg["H"], W=cfg["W"], K=K, Wm=Wm, S=S, KS=KS,
+               elapsed=elapsed, first_elapsed=first_elapsed, effective_warmup=effective_warmup,
+               maps_per_s=world * K / elapsed, ms_per_step=elapsed / K * 1e3, per_rank=list(per_rank),
+               stages=stages, roofline=roofline, path_bytes=path_bytes, path_flops=path_flops,
+               stagewise_floor_s=stagewise_floor_s, executed_floor_s=executed_floor_s, in_image_frac=in_image_frac,
+               call=("staged C-ABI calls with HIP events" if staged_timed else "one mvs_depth_infer call per map"),
+               last_depth=out[K - 1, 0], inputs=(feats_np, proj_np, dv_np, sd), streams=streams)
+    return res
+
+
+def brief(res, world=1):
+    """The `other_configs` entry of one further BASELINE config (same two-pass timing as `value`, path-only)."""
+    st = res["stages"]
+    dom = res["roofline"]
+    out = {"value": round(res["maps_per_s"], 2), "unit": "depth maps/s", "ms_per_step": round(res["ms_per_step"], 4),
+           "first_pass": round(world * res["K"] / res["first_elapsed"], 2), "steps": res["K"],
+           "effective_warmup_steps": res["effective_warmup"],
+           "dtype": f"{res['storage']} storage and MFMA operands, f32 accumulation" if res["storage"] != "f32" else "f32",
+           "workload": f"{res['config']}: N={res['N']} views, {res['H']}x{res['W']} image -> {res['h']}x{res['w']} "
+                       f"features, D={res['D']}, {res['storage']} volumes; path-only",
+           "frac_of_stagewise_roofline": round(res["stagewise_floor_s"] / (res["elapsed"] / res["K"]), 4),
+           "frac_of_executed_roofline": round(res["executed_floor_s"] / (res["elapsed"] / res["K"]), 4),
+           "hbm_GBps_algorithmic": round(res["path_bytes"] * res["maps_per_s"] / 1e9, 1),
+           "in_image_frac": res["in_image_frac"]}
+    if dom:
+        out["dominant"] = {k: dom[k] for k in ("kernel", "bound", "achieved", "unit", "frac", "avg_launch_ms", "traffic")
+                           if k in dom}
+    out["stages_ms"] = {n: e["ms"] for n, e in st.items()}
+    out["stages_frac"] = {n: e["frac"] for n, e in st.items() if "frac" in e}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from scene_3dreconstruction_mvsnet_amd import _lib, sharding, synthetic
+    # one process per GPU: keep this rank's host threads on the cores next to its GPU (before any GPU call)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    pinned = sharding.pin_rank(local_rank, local_world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    # MVS_BENCH_REHEARSAL=1: run every rank on cuda:0 with the gloo backend -- a way to exercise
+    # the N>1 code path on a one-GPU box (numbers are meaningless; the driver never sets it)
+    rehearsal = os.environ.get("MVS_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    pin_check = None
+    if pinned and not rehearsal:
+        # is the GPU HIP gave this rank the one whose cores were chosen from sysfs before HIP was up?
+        pr = torch.cuda.get_device_properties(dev_index)
+        pin_check = sharding.verify_pinning(local_rank, f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
+        if not pin_check["match"]:
+            print(f"[bench] rank {rank}: pinned to the cores of {pin_check['assumed_bus_id']} but HIP device "
+                  f"{dev_index} is {pin_check['hip_bus_id']} (affinity only; results unaffected)", file=sys.stderr)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = Ctx()
+    ctx.torch, ctx.dist, ctx._lib, ctx.sharding, ctx.synthetic = torch, dist, _lib, sharding, synthetic
+    ctx.dev, ctx.rank, ctx.world, ctx.rehearsal = dev, rank, world, rehearsal
+    _lib.load()
+
+    K, Wm = args.steps, args.warmup
+    storage = args.dtype or {"cfg3": "bf16", "cfg5": "f16"}.get(args.config, "f32")
+    S = max(1, args.streams)
+    prewarm_ms = max(0, args.prewarm_ms)
+    KS = max(0, args.staged_steps)
+    res = measure(ctx, args.config, storage, K, Wm, prewarm_ms, S, KS, staged_timed=args.staged_timed)
+    N, D, h, w = res["N"], res["D"], res["h"], res["w"]
+    cfg = synthetic.CONFIGS[args.config]
+    maps_per_s, ms_per_step, elapsed, first_elapsed = res["maps_per_s"], res["ms_per_step"], res["elapsed"], res["first_elapsed"]
+    stages, roofline, streams = res["stages"], res["roofline"], res["streams"]
+    feats_np, proj_np, dv_np, sd = res["inputs"]
+
+    # ---- the other single-GPU BASELINE configs (cfg3: bf16 1600x1184x256; cfg5: fp16 N=4), path-only, same two-pass
+    # timing, in this process right after the metric's own timed region.  They are parity-test cases and a report,
+    # never `value`.  One-GPU runs of the default config only; K scaled so each costs about a second of GPU time.
+    other_configs = None
+    if args.config == "cfg2" and storage == "f32" and world == 1 and not args.no_other_configs:
+        other_configs = {}
+        for oc, ost, ok in (("cfg3", "bf16", max(4, min(K, 20))), ("cfg5", "f16", max(4, min(2 * K, 60)))):
+            torch.cuda.empty_cache()
+            try:
+                r = measure(ctx, oc, ost, ok, Wm, prewarm_ms, S, min(KS, 5))
+                other_configs[oc] = brief(r, world)
+                del r
+            except RuntimeError as e:      # report, never hide: the default line must still print
+                other_configs[oc] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline (rank 0, N=1): the oracle on one full map of the same workload ---------
     cpu_baseline = None
@@ -475,7 +608,7 @@ def main(argv=None):
                         "kind": "port",
                         "sample": f"1 full {args.config} map (N={N}, {h}x{w}x{D}) through oracle/ "
                                   f"(C + OpenMP restatement), {tc:.1f} s"}
-        got = out[K - 1, 0].cpu().numpy()
+        got = res["last_depth"].cpu().numpy()
         parity = float(np.abs(got - depth_o).mean() / np.abs(depth_o).mean())
 
     # ---- end-to-end figure, outside the timed region, never `value`: the drop-in
@@ -491,21 +624,35 @@ def main(argv=None):
         model.storage_dtype = storage
         imgs_np, proj_i, dv_i = synthetic.make_inputs(N, cfg["H"], cfg["W"], D, seed=0,
                                                       interval_scale=cfg["interval_scale"])
+        # the reference's loader makes these floats from 8-bit pixels (np.array(img, float32) / 255,
+        # datasets/data_io.py:143): the uint8 form of the same images is what `h2d_uint8` copies
+        imgs_u8_np = np.clip(np.rint(imgs_np * 255.0), 0, 255).astype(np.uint8)
+        imgs_np = imgs_u8_np.astype(np.float32) / np.float32(255.0)
         imgs_h = torch.from_numpy(imgs_np).pin_memory()
+        imgs_u8_h = torch.from_numpy(imgs_u8_np).pin_memory()
         proj_i, dv_i = torch.from_numpy(proj_i).to(dev), torch.from_numpy(dv_i).to(dev)
         end_to_end = {"unit": "depth maps/s", "includes": "FeatureNet (HIP) + path; h2d adds the "
-                      "pinned-host -> HBM copy of the N images on the same stream; K maps after "
-                      f"{prewarm_ms} ms of the same calls (untimed)"}
+                      "pinned-host -> HBM copy of the N float32 images on the same stream, h2d_uint8 copies the same "
+                      "images as uint8 (4x fewer bytes; the division by 255 happens in FeatureNet's first kernel, "
+                      f"bit-equal to the reference's loader); K maps after {prewarm_ms} ms of the same calls (untimed)"}
         # like the path-only figure: forwards round-robin over the S streams (the module keeps one workspace per
         # stream); in h2d mode every forward first copies its own images on its stream
+        S_ = len(streams)
+        accepts_u8 = getattr(MVSNet, "ACCEPTS_UINT8_IMAGES", False)
+
         def e2e_forward(i, mode):
-            with torch.cuda.stream(streams[i % S]):
-                x_d = imgs_h.to(dev, non_blocking=True) if mode == "h2d" else imgs_d
+            with torch.cuda.stream(streams[i % S_]):
+                if mode == "h2d":
+                    x_d = imgs_h.to(dev, non_blocking=True)
+                elif mode == "h2d_uint8":
+                    x_d = imgs_u8_h.to(dev, non_blocking=True)
+                else:
+                    x_d = imgs_d
                 model(x_d, proj_i, dv_i)
 
-        for mode in ("resident", "h2d"):
+        for mode in ("resident", "h2d") + (("h2d_uint8",) if accepts_u8 else ()):
             imgs_d = imgs_h.to(dev)
-            for i in range(3 * S):
+            for i in range(3 * S_):
                 e2e_forward(i, mode)
             torch.cuda.synchronize()
             tp = time.perf_counter()
@@ -518,31 +665,32 @@ def main(argv=None):
                 e2e_forward(i, mode)
             torch.cuda.synchronize()
             end_to_end[mode] = round(K / (time.perf_counter() - te), 2)
-        end_to_end["streams"] = S
+        end_to_end["streams"] = S_
 
-    # live PMC measurement of the dominant kernel's HBM traffic (rank 0 of a one-GPU cfg2 run; after every timing)
-    if (rank == 0 and world == 1 and roofline is not None and args.config == "cfg2" and storage == "f32"
-            and not args.no_live_traffic and roofline["kernel"] in ("conv0", "warp_variance")):
+    # live PMC measurement of the dominant kernel's HBM traffic (rank 0 of a one-GPU run; after every timing)
+    if (rank == 0 and world == 1 and roofline is not None and not args.no_live_traffic
+            and roofline["kernel"] in TRAFFIC_KERNELS):
         torch.cuda.synchronize()
-        sub = {"conv0": "conv0_w43_mfma_kernel" if wino == "4" else "conv0_4x4_mfma_kernel",
-               "warp_variance": "warp_variance_tc2_kernel"}[roofline["kernel"]]
+        sub, what, factor = TRAFFIC_KERNELS[roofline["kernel"]]
         t_live = time.perf_counter()
-        live = live_traffic(sub, "conv0" if roofline["kernel"] == "conv0" else "warp")
+        live = live_traffic(sub, what, cfg=args.config, storage=storage, fetch_factor=factor)
         if live:
             roofline["traffic"] = live
             roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child "
-                                          "passes, --kernel-trace only) over tools/prof_stage.py, per launch; FETCH x2 gfx950 "
-                                          f"correction; {time.perf_counter() - t_live:.0f} s")
+                                          f"passes, --kernel-trace only) over tools/prof_stage.py {what} 3 {args.config} {storage}, "
+                                          f"per launch; FETCH x{factor:g} (gfx950 correction for this kernel's load pattern); "
+                                          f"{time.perf_counter() - t_live:.0f} s")
 
     if rank == 0:
+        conv0_split = storage == "f32" and os.environ.get("MVS_CONV0_SPLIT") == "1"
         line = {
             "metric": "depth maps/sec at N=5 views, 640x512, D=192; achieved HBM GB/s"
                       if args.config == "cfg2" else f"depth maps/sec ({args.config})",
             "value": round(maps_per_s, 3), "unit": "depth maps/s", "n_gpus": world, "steps": K,
-            "warmup": Wm, "effective_warmup_steps": effective_warmup,
+            "warmup": Wm, "effective_warmup_steps": res["effective_warmup"],
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if storage == "f32" else (
+            "dtype": ("f32 (conv0: 3xbf16 split operands, fp32 accumulate)" if conv0_split else "f32") if storage == "f32" else (
                 f"{storage} storage, f32 MFMA arithmetic" if os.environ.get("MVS_MFMA16") == "0"
                 else f"{storage} storage and MFMA operands, f32 accumulation"),
             "data": "synthetic",
@@ -551,26 +699,32 @@ def main(argv=None):
                                    "resident in HBM -> depth+confidence)",
                        "maps_per_rank": K, "sharding": "independent ref views per rank, one RCCL "
                                                        "all-gather of results at the end",
-                       "call": ("staged C-ABI calls with HIP events" if step_one is step_staged else
-                                "one mvs_depth_infer call per map") +
+                       "call": res["call"] +
                                (f"; per-kernel durations from {KS} further maps through the per-stage C-ABI "
                                 "calls with HIP events, after the timed region" if KS else ""),
-                       "in_image_frac": in_image_frac,
+                       "in_image_frac": res["in_image_frac"],
                        "prewarm_ms": prewarm_ms,
                        "streams": S},
             "first_pass": {"value": round(world * K / first_elapsed, 3), "ms_per_step": round(first_elapsed / K * 1e3, 4),
                            "note": f"the same {K} steps timed right after the {Wm} warm-up steps, before the device "
                                    f"clocks had settled; `value` is the same pass repeated after {prewarm_ms} ms of "
                                    "the same workload (untimed)"},
-            "hbm_GBps_algorithmic": round(path_bytes * maps_per_s / 1e9, 1),
-            "hbm_frac_of_peak": round(path_bytes * maps_per_s / 1e9 / (HBM_PEAK_GBPS * world), 4),
-            "path": {"algorithmic_bytes": path_bytes, "algorithmic_flops": path_flops,
-                     "stagewise_roofline_ms": round(stagewise_floor_s * 1e3, 4),
-                     "frac_of_stagewise_roofline": round(stagewise_floor_s / (elapsed / K), 4)},
-            "per_rank": {"maps_per_s": [round(K / t, 2) for t in per_rank], "host_cores": len(pinned) or None,
+            "hbm_GBps_algorithmic": round(res["path_bytes"] * maps_per_s / 1e9, 1),
+            "hbm_frac_of_peak": round(res["path_bytes"] * maps_per_s / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "path": {"algorithmic_bytes": res["path_bytes"], "algorithmic_flops": res["path_flops"],
+                     "stagewise_roofline_ms": round(res["stagewise_floor_s"] * 1e3, 4),
+                     "frac_of_stagewise_roofline": round(res["stagewise_floor_s"] / (elapsed / K), 4),
+                     "executed_roofline_ms": round(res["executed_floor_s"] * 1e3, 4),
+                     "frac_of_executed_roofline": round(res["executed_floor_s"] / (elapsed / K), 4),
+                     "note": "stagewise = SURVEY d3 algorithmic bytes / FLOPs per stage; executed = what this build's "
+                             "kernels issue and move (Winograd layers fewer multiply-adds, fused tail once, fp32 logits "
+                             "in the 16-bit modes)"},
+            "per_rank": {"maps_per_s": [round(K / t, 2) for t in res["per_rank"]], "host_cores": len(pinned) or None,
+                         "pin_check": pin_check,
                          "note": "each rank's K maps / its own clock around the timed region (barriers and the "
                                  "gather included); `value` = world*K / the slowest"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "end_to_end": end_to_end, "stages": stages,
+            "other_configs": other_configs,
             "parity_rel_l1_vs_oracle": parity,
         }
         print(json.dumps(line), flush=True)

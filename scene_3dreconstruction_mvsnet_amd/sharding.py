@@ -66,12 +66,13 @@ def _parse_cpulist(text: str) -> list:
     return cpus
 
 
-def gpu_local_cpus(sysfs_root: str = "/sys") -> list:
+def gpu_local_cpus(sysfs_root: str = "/sys", with_ids: bool = False):
     """`local_cpulist` of every AMD display/accelerator PCI function, in PCI bus order (the order HIP
-    enumerates devices in by default).  Reads sysfs only -- no HIP call, safe before a fork/exec."""
+    usually enumerates devices in; `check_gpu_order` verifies it once HIP is up).  Reads sysfs only -- no HIP
+    call, safe before a fork/exec.  with_ids: also return the PCI addresses ("0000:05:00.0") in the same order."""
     import glob
     import os
-    out = []
+    out, ids = [], []
     for dev in sorted(glob.glob(os.path.join(sysfs_root, "bus/pci/devices/*"))):
         try:
             with open(os.path.join(dev, "vendor")) as f:
@@ -82,9 +83,10 @@ def gpu_local_cpus(sysfs_root: str = "/sys") -> list:
                 continue
             with open(os.path.join(dev, "local_cpulist")) as f:
                 out.append(_parse_cpulist(f.read()))
+            ids.append(os.path.basename(dev))
         except (OSError, ValueError):
             continue
-    return out
+    return (out, ids) if with_ids else out
 
 
 def rank_cpus(local_rank: int, local_world: int, allowed: list, gpu_cpus: list | None = None) -> list:
@@ -107,23 +109,41 @@ def rank_cpus(local_rank: int, local_world: int, allowed: list, gpu_cpus: list |
 
 
 def visible_gpu_order(n_physical: int, environ=None) -> list:
-    """Physical indices of the GPUs this process sees, in the order HIP numbers them: the launcher may have
-    narrowed or permuted them with ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (integer
-    lists; anything else -- UUIDs, an empty value -- leaves the physical order)."""
+    """Physical indices of the GPUs this process sees, in the order HIP numbers them.  The launcher may have
+    narrowed or permuted them: ROCR_VISIBLE_DEVICES acts on the runtime below HIP; on top of that the HIP runtime
+    honours HIP_VISIBLE_DEVICES, and CUDA_VISIBLE_DEVICES only as its ALIAS when HIP_VISIBLE_DEVICES is unset (both
+    set to the same permutation is one re-indexing, not two).  Integer lists only; anything else -- UUIDs, an
+    empty value, an index out of range -- leaves the order as it was."""
     import os
     env = os.environ if environ is None else environ
-    order = list(range(n_physical))
-    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):   # applied in this order
-        val = env.get(name)
-        if not val:
-            continue
+
+    def apply(order, val):
         try:
             idx = [int(t) for t in val.split(",") if t.strip() != ""]
         except ValueError:
-            continue
+            return order
         if idx and all(0 <= i < len(order) for i in idx):
-            order = [order[i] for i in idx]
+            return [order[i] for i in idx]
+        return order
+
+    order = list(range(n_physical))
+    if env.get("ROCR_VISIBLE_DEVICES"):
+        order = apply(order, env["ROCR_VISIBLE_DEVICES"])
+    hip = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+    if hip:
+        order = apply(order, hip)
     return order
+
+
+def check_gpu_order(gpu_cpus_sysfs_order: list, sysfs_bus_ids: list, hip_bus_ids: list) -> list:
+    """After the first GPU call: HIP's own PCI bus ids against the sorted-sysfs order `gpu_local_cpus` assumed
+    (ROCr does not promise to enumerate in PCI address order).  Returns the per-HIP-device cpu lists re-ordered by
+    bus id, or the input when an id is unknown; callers log a mismatch (affinity only -- results are unaffected)."""
+    pos = {b.lower(): i for i, b in enumerate(sysfs_bus_ids)}
+    try:
+        return [gpu_cpus_sysfs_order[pos[b.lower()]] for b in hip_bus_ids]
+    except KeyError:
+        return gpu_cpus_sysfs_order
 
 
 def pin_rank(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> list:
@@ -138,3 +158,14 @@ def pin_rank(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> lis
     if cpus:
         os.sched_setaffinity(0, cpus)
     return cpus
+
+
+def verify_pinning(local_rank: int, hip_bus_id: str, sysfs_root: str = "/sys") -> dict:
+    """After the first GPU call: is the GPU HIP gave this rank the one whose cores `pin_rank` chose?  Compares
+    the device's PCI address as HIP reports it with the sorted-sysfs entry `pin_rank` assumed for `local_rank`.
+    Affinity only -- a mismatch is reported (bench.py prints it), never fatal."""
+    _, ids = gpu_local_cpus(sysfs_root, with_ids=True)
+    order = visible_gpu_order(len(ids))
+    assumed = ids[order[local_rank]] if local_rank < len(order) and order[local_rank] < len(ids) else None
+    return {"hip_bus_id": hip_bus_id, "assumed_bus_id": assumed,
+            "match": (assumed is not None and assumed.lower() == hip_bus_id.lower())}

@@ -179,9 +179,15 @@ def test_cfg2_layer_test_would_catch_a_dropped_tap(cfg2):
 
 
 # ------------------------------------------------------------------ cfg3 / cfg5 (BASELINE configs 2 / 4)
-@pytest.mark.parametrize("cfg_name,storage", [("cfg5", "f16"), ("cfg3", "bf16")])
+_FP32_ORACLE = {}   # cfg -> (var32, d32): the cfg3 oracle run (~20 s, 3.9 GB) is shared by its bf16 and fp32 cases
+
+
+@pytest.mark.parametrize("cfg_name,storage", [("cfg5", "f16"), ("cfg3", "bf16"), ("cfg3", "f32")])
 def test_16bit_configs_per_stage_and_against_the_fp32_oracle(cfg_name, storage):
-    """configs[4] (N=4, fp16) and configs[2] (N=5, 1600x1184, D=256, bf16) at full size:
+    """configs[4] (N=4, fp16) and configs[2] (N=5, 1600x1184, D=256, bf16) at full size -- and configs[2]'s shape with
+    fp32 volumes, the largest fp32 problem of the suite (3.88 GB variance volume: the 31-bit-offset guards of the
+    conv kernels, the raw-buffer stores of the warp kernel beyond 2 GiB, and the fp32 kernels that only large
+    shapes select -- depth-slab-fastest warp order, z-marching conv1, the chunk split of the fused tail):
       * the variance volume against the oracle with the same rounding points -- at cfg3 this is the
         depth-slab-fastest block order of the warp kernels, which small shapes never select;
       * depth against the rounding-matched oracle (tight) AND against the plain fp32 oracle, where
@@ -194,7 +200,11 @@ def test_16bit_configs_per_stage_and_against_the_fp32_oracle(cfg_name, storage):
     sd = synthetic.random_costreg_state(seed=2)
     code = _lib.dtype_code(storage)
 
-    var32 = orc.variance_volume(feats, proj, dv)                       # the fp32 reference volume
+    if cfg_name not in _FP32_ORACLE:
+        _FP32_ORACLE.clear()
+        v = orc.variance_volume(feats, proj, dv)                       # the fp32 reference volume
+        _FP32_ORACLE[cfg_name] = (v, orc.softargmin_conf(orc.costreg_forward(v, sd), dv)[0])
+    var32, d32 = _FP32_ORACLE[cfg_name]
     var_m = var32 if storage == "f32" else orc.round_storage(
         orc.variance_volume(orc.round_storage(feats, storage), proj, dv), storage)
     got = _lib.from_c8(hip_variance_c8(feats, proj, dv, code).float()).cpu().numpy()
@@ -208,11 +218,11 @@ def test_16bit_configs_per_stage_and_against_the_fp32_oracle(cfg_name, storage):
     _lib.depth_infer(cu(feats), cu(proj), cu(dv), _lib.pack_weights(sd).to(DEV), ws, depth, conf, dtype=code)
     depth = depth.cpu().numpy()
     assert np.isfinite(depth).all()
-    d32, _, _ = orc.softargmin_conf(orc.costreg_forward(var32, sd), dv)
     r32 = rel_l1(depth, d32)
     print(f"[{cfg_name} {storage}] depth rel-L1 vs the fp32 oracle = {r32:.3e}")
     if storage == "f32":
         assert r32 < 5e-6, r32
+        _FP32_ORACLE.clear()
         return
     d_m, _, _ = orc.softargmin_conf(orc.costreg_forward(var_m, sd, storage, arith16=True), dv)
     rm = rel_l1(depth, d_m)

@@ -1,5 +1,5 @@
 # the three PMC passes of tools/gpu/session.sh for another BASELINE config: bash tools/gpu/pmc_cfg.sh cfg3 bf16
-# -> gpurun_out/traffic_$1 (merge with: python tools/pmc_summary.py gpurun_out/traffic_cfg3 > profiles/rNN_traffic_cfg3.json)
+# -> gpurun_out/traffic_$1 (merge with: python tools/pmc_summary.py gpurun_out/traffic_cfg3 cfg3 bf16 > profiles/rNN_traffic_cfg3.json)
 set -e
 R=$GRAFT_REPO_ROOT
 C=${1:-cfg3}

@@ -7,7 +7,7 @@ Collect (each pass separately, counters never mixed with sys/hip traces):
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT/write -- python3 tools/prof_stage.py all 3
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \\
               SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d OUT/sq -- python3 ...
-Then:  python tools/pmc_summary.py OUT > profiles/rNN_traffic.json
+Then:  python tools/pmc_summary.py OUT [cfg2|cfg3|cfg5] [f32|f16|bf16] > profiles/rNN_traffic[_cfgN].json
 FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB per count as rocprofv3 reports them; the gfx950
 correction (FETCH_SIZE under-reports wide 16 B/lane streaming reads by 2x, MI355X_MICROARCH.md HBM
 section) is applied in `hbm_bytes_fetch_x2`.
@@ -20,6 +20,8 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+storage = sys.argv[3] if len(sys.argv) > 3 else {"cfg3": "bf16", "cfg5": "f16"}.get(cfg_name, "f32")
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
@@ -30,8 +32,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             short = name.rsplit("(", 1)[0].replace("void ", "").replace("(anonymous namespace)::", "")
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, each with "
-                 "--kernel-trace only) over tools/prof_stage.py all 3 (cfg2, fp32), MI355X; merged by "
-                 "tools/pmc_summary.py",
+                 f"--kernel-trace only) over tools/prof_stage.py all 3 {cfg_name} {storage}, MI355X; merged by "
+                 f"tools/pmc_summary.py OUT {cfg_name} {storage}",
        "note": "FETCH_SIZE under-reports wide coalesced 16 B/lane streaming reads by 2x on gfx950 "
                "(MI355X_MICROARCH.md, HBM section); hbm_bytes_fetch_x2 applies that correction, valid for "
                "the staging loads of the conv kernels, not for the tap gathers of the warp kernel.  "
