@@ -464,8 +464,17 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
             const char* e = getenv("MVS_CONV0_WINO");
             return !(e && e[0] == '0');
         }();
-        if (wino && Di % 4 == 0 && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31))
+        // MVS_CONV0_SPLIT=1: the same F(4,3) scheme with every operand split into three bf16 pieces, six cross
+        // products per fp32 product on the bf16 matrix cores, fp32 accumulation (conv0_split.hip; fp32 volumes only)
+        static const bool split = [] {
+            const char* e = getenv("MVS_CONV0_SPLIT");
+            return e && e[0] == '1';
+        }();
+        if (wino && Di % 4 == 0 && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31)) {
+            if (split && dtype == MVS_F32)
+                return launch_conv0_wino43_split(x, y, blob + L.c0w43s_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
             return launch_conv0_wino43(x, y, blob + L.c0w43_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
+        }
         return launch_conv0_mfma(x, y, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
     }
     if (layer == 2 || layer == 4) {

@@ -44,6 +44,7 @@ struct BlobLayout {
     size_t h16_off[2][10];         // 16-bit MFMA panels of layers 0..9 for MVS_F16 ([0]) / MVS_BF16 ([1])
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv_winograd.hip)
     size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv_winograd.hip)
+    size_t c0w43s_off;             // the same weights as three bf16 pieces, Toeplitz panel [4][6][3][3][64][8] (conv0_split.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -81,6 +82,8 @@ inline BlobLayout blob_layout() {
     }
     L.c0w43_off = off;
     off += (size_t)4 * 6 * 9 * 2 * 2 * 4 * 4;
+    L.c0w43s_off = off;
+    off += (size_t)4 * 6 * 3 * 3 * 64 * 8 / 2;
     L.total_floats = off;
     return L;
 }
@@ -231,6 +234,10 @@ int launch_conv_layer_direct(int layer, const void* x, const void* skip, void* y
 int launch_conv0_wino43(const void* x, void* y, const float* bw, const float* bias, int D, int H, int W,
                         int dtype, hipStream_t s);
 void pack_conv0_wino43_weights(const float* wfold, float* bw);
+// conv0 with split bf16 operands on the 16-bit matrix cores, fp32 volumes (conv0_split.hip)
+int launch_conv0_wino43_split(const void* x, void* y, const void* bp, const float* bias, int D, int H, int W,
+                              int dtype, hipStream_t s);
+void pack_conv0_wino43_split_weights(const float* wfold, void* out);
 int launch_convwz_mfma(int layer, const void* x, void* y, const float* bp, const float* bias, int D, int H,
                        int W, int dtype, hipStream_t s);
 void pack_convwz_weights(const float* wfold, int cin, int cout, float* bp);

@@ -149,6 +149,22 @@ def test_pack_weights_folds_bn_and_relayouts():
         np.testing.assert_allclose(w43[c, t, tap, half, nt, j, k], G43[t][tap, 8 * c + 4 * half + k, 4 * nt + j],
                                    rtol=1e-6, atol=1e-9)
     off += 4 * 6 * 9 * 2 * 2 * 4 * 4
+    # the same transformed weights as three bf16 pieces, Toeplitz-pair panel [4][6 t][3 ky][3 pieces][64 lanes][8]
+    # (conv0_split.hip): the pieces of every weight add up to the fp32 value to <= 2^-24 of it; columns with
+    # kx = g - jj outside [0, 2] are zero
+    n16 = 4 * 6 * 3 * 3 * 64 * 8
+    ps = blob[off:off + n16 // 2].view(np.uint16).reshape(4, 6, 3, 3, 64, 8)
+    pf = (ps.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    for c, t, ky, lane, j in [(0, 0, 0, 0, 0), (3, 5, 2, 63, 7), (1, 1, 1, 21, 3), (2, 3, 0, 40, 5), (0, 4, 2, 9, 1),
+                              (3, 2, 1, 55, 6), (1, 0, 0, 8, 0), (2, 5, 1, 31, 4)]:
+        n, gq = lane & 15, lane >> 4
+        jj, co, kx = n >> 3, n & 7, (lane >> 4) - ((lane & 15) >> 3)
+        want = float(np.float32(G43[t][ky * 3 + kx, 8 * c + j, co])) if 0 <= kx <= 2 else 0.0
+        got = pf[c, t, ky, :, lane, j]
+        assert abs(got.sum() - want) <= 2.0 ** -24 * abs(want), (c, t, ky, lane, j, got, want)
+        if want != 0.0:
+            assert abs(got[1]) <= 2.0 ** -8 * abs(want) and abs(got[2]) <= 2.0 ** -16 * abs(want)
+    off += n16 // 2
     assert off * 4 == _lib.query_weights_blob()
 
 
