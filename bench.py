@@ -99,6 +99,13 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
         if env.get("MVS_FORCE_DIRECT") != "1":
             if env.get("MVS_CONV0_WINO") != "0" and D % 4 == 0 and V0 * 32 < (1 << 31):
                 ex["conv0"]["flops"] = costs["conv0"]["flops"] * 0.5
+                if conv0_split_enabled(env):
+                    # split operands (csrc/conv0_split.hip): six bf16 cross products per fp32 product, Toeplitz-pair
+                    # form (4 x-taps issued per 3 real ones), on the bf16 matrix cores: 1/2 x 6 x 4/3 = 4x the
+                    # algorithmic multiply-adds, priced against the bf16 MFMA peak
+                    ex["conv0"]["flops"] = costs["conv0"]["flops"] * 4.0
+                    ex["conv0"]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
+                    ex["conv0"]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"
             if env.get("MVS_CONV_WINO") != "0":
                 for n in ("conv2", "conv4"):
                     ex[n]["flops"] = costs[n]["flops"] * 20.0 / 27.0
@@ -106,6 +113,12 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
         for n in ("prob", "conv11_prob", "softargmin"):
             ex[n]["bytes"] = costs[n]["bytes"] + V0 * 2
     return ex
+
+
+def conv0_split_enabled(env=None):
+    """conv0 of the fp32 path runs with split bf16 operands unless MVS_CONV0_SPLIT=0 (csrc/conv3d_direct.hip)."""
+    env = os.environ if env is None else env
+    return env.get("MVS_CONV0_SPLIT") != "0"
 
 
 def stage_entry(ms, c_alg, c_ex, mfma_peak):
@@ -118,9 +131,11 @@ def stage_entry(ms, c_alg, c_ex, mfma_peak):
     ent["GBps"] = round(c_alg["bytes"] / ms / 1e6, 1)
     if c_alg["flops"]:
         ent["TFLOPs"] = round(c_alg["flops"] / ms / 1e9, 2)
-    t_hbm, t_mfma = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e6), c_ex["flops"] / (mfma_peak * 1e9)
+    t_hbm, t_mfma = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e6), c_ex["flops"] / (c_ex.get("mfma_peak", mfma_peak) * 1e9)
     ent["bound"] = "mfma" if t_mfma > t_hbm else "hbm"
     ent["frac"] = round(max(t_hbm, t_mfma) / ms, 3)
+    if "arith" in c_ex:
+        ent["arith"] = c_ex["arith"]
     alg_ms = max(c_alg["bytes"] / (HBM_PEAK_GBPS * 1e6), c_alg["flops"] / (mfma_peak * 1e9))
     ent["frac_algorithmic"] = round(alg_ms / ms, 3)
     return ent
@@ -131,15 +146,23 @@ def roofline_entry(dom, ms, c_alg, c_ex, mfma_peak):
     or HBM really did per second); the algorithmic rate of SURVEY d3 travels as `achieved_algorithmic` /
     `algorithmic_ratio` (not a fraction of peak: > 1 is possible for a Winograd kernel)."""
     t_hbm = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e9)
-    t_mfma = c_ex["flops"] / (mfma_peak * 1e12)
+    ex_peak = c_ex.get("mfma_peak", mfma_peak)     # peak of the matrix unit the kernel really runs on
+    t_mfma = c_ex["flops"] / (ex_peak * 1e12)
     if t_mfma > t_hbm:
         ach, alg = c_ex["flops"] / ms / 1e9, c_alg["flops"] / ms / 1e9
-        r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": mfma_peak, "unit": "TFLOP/s",
-             "frac": round(ach / mfma_peak, 4), "traffic": None, "avg_launch_ms": ms,
+        r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": ex_peak, "unit": "TFLOP/s",
+             "frac": round(ach / ex_peak, 4), "traffic": None, "avg_launch_ms": ms,
              "achieved_algorithmic": round(alg, 3), "algorithmic_ratio": round(alg / mfma_peak, 4),
              "algorithmic_flops": c_alg["flops"], "executed_flops": c_ex["flops"],
              "algorithmic_bytes": c_alg["bytes"]}
-        if c_ex["flops"] != c_alg["flops"]:
+        if "arith" in c_ex:
+            r["note"] = (f"{dom}: {c_ex['arith']} on the bf16 matrix cores (Winograd F(4,3) along z, Toeplitz-pair form): "
+                         f"it issues {c_ex['flops'] / c_alg['flops']:.2f}x the algorithmic multiply-adds as bf16 MFMA work; "
+                         f"`frac` = executed bf16 MFMA flops / time / the bf16 peak ({ex_peak:g} TF); `algorithmic_ratio` = "
+                         f"algorithmic fp32 flops / time / the fp32 MFMA peak ({mfma_peak:g} TF; it exceeds 1: the fp32 "
+                         "matrix pipe is no longer what bounds this layer).  HBM floor of the layer: "
+                         f"{c_ex['bytes'] / HBM_PEAK_GBPS / 1e6:.3f} ms")
+        elif c_ex["flops"] != c_alg["flops"]:
             r["note"] = (f"{dom} runs a Winograd transform along z: it issues {c_ex['flops'] / c_alg['flops']:.3f} of "
                          "the algorithmic multiply-adds; `frac` = executed MFMA flops / time / peak")
     else:
@@ -489,8 +512,8 @@ def measure(ctx, config, storage, K, Wm, prewarm_ms, S, KS, staged_timed=False):
     # ran; the executed floor prices what this build's kernels really issue / move (fused tail counted once)
     path_bytes, path_flops, stagewise_floor_s = path_totals(costs, mfma_peak)
     ran = [n for n in stage_names if n in ex_costs]
-    executed_floor_s = sum(max(ex_costs[n]["bytes"] / (HBM_PEAK_GBPS * 1e9), ex_costs[n]["flops"] / (mfma_peak * 1e12))
-                           for n in ran)
+    executed_floor_s = sum(max(ex_costs[n]["bytes"] / (HBM_PEAK_GBPS * 1e9),
+                               ex_costs[n]["flops"] / (ex_costs[n].get("mfma_peak", mfma_peak) * 1e12)) for n in ran)
     res = dict(config=config, storage=storage, N=N, D=D, h=h, w=w, H=cfg["H"], W=cfg["W"], K=K, Wm=Wm, S=S, KS=KS,
                elapsed=elapsed, first_elapsed=first_elapsed, effective_warmup=effective_warmup,
                maps_per_s=world * K / elapsed, ms_per_step=elapsed / K * 1e3, per_rank=list(per_rank),
@@ -682,7 +705,8 @@ def main(argv=None):
                                           f"{time.perf_counter() - t_live:.0f} s")
 
     if rank == 0:
-        conv0_split = storage == "f32" and os.environ.get("MVS_CONV0_SPLIT") == "1"
+        conv0_split = (storage == "f32" and conv0_split_enabled() and os.environ.get("MVS_FORCE_DIRECT") != "1"
+                       and os.environ.get("MVS_CONV0_WINO") != "0" and D % 4 == 0)
         line = {
             "metric": "depth maps/sec at N=5 views, 640x512, D=192; achieved HBM GB/s"
                       if args.config == "cfg2" else f"depth maps/sec ({args.config})",

@@ -5,8 +5,9 @@
  * binds (ctypes) to replace, for inference, the torch ops dispatched by
  *   models/mvsnet.py:145-218  (cost volume -> CostRegNet -> soft-argmin / confidence)
  *   models/module.py:96-147   (homo_warping, depth_regression)
- * of /root/reference.  FeatureNet (models/mvsnet.py:10-30) stays on PyTorch-ROCm and hands
- * its NCHW fp32 output to mvs_warp_variance / mvs_depth_infer.
+ * of /root/reference.  FeatureNet (models/mvsnet.py:10-30) is part of the library as well (mvs_feature_net,
+ * mvs_forward_images: csrc/featnet.hip); a caller that keeps its own FeatureNet hands its NCHW fp32 output to
+ * mvs_warp_variance / mvs_depth_infer instead.
  *
  * Conventions
  *  - extern "C", plain pointers and ints; no torch / C++ types.
@@ -31,7 +32,11 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 1
+/* 2 (round 4): + mvs_feature_net_fmt / mvs_forward_images_fmt (uint8 images); mvs_warp_conv0 removed (it left in round
+ * 3 without a bump); the packed weight blob grew (split-operand conv0 panel) and lost the round-2 conv0 panels.
+ * A packed blob (mvs_pack_weights / mvs_pack_feature_weights) is valid ONLY for the library version that produced it:
+ * never cache one across builds -- re-pack from the state_dict (4 MB, milliseconds). */
+#define MVS_ABI_VERSION 2
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -42,6 +47,15 @@ typedef enum mvs_status {
     MVS_ERR_HIP = 4,         /* a HIP runtime call failed (launch error ...) */
     MVS_ERR_NULL = 5         /* required pointer is NULL */
 } mvs_status;
+
+/* pixel format of the images handed to mvs_feature_net_fmt / mvs_forward_images_fmt.  The uint8 forms are the decoded
+ * image as the reference's loader holds it BEFORE `np.array(img, dtype=np.float32) / 255.` (datasets/data_io.py:143);
+ * the library performs that IEEE division itself (bit-equal), so a caller copies a quarter of the bytes to the device. */
+typedef enum mvs_image_format {
+    MVS_IMG_F32_CHW = 0,     /* float32 [N][3][H][W] in [0,1]: the tensor MVSNet.forward receives (models/mvsnet.py:103) */
+    MVS_IMG_U8_CHW = 1,      /* uint8 [N][3][H][W] */
+    MVS_IMG_U8_HWC = 2       /* uint8 [N][H][W][3], as PIL / np.array(img) yields it (datasets/data_io.py:143) */
+} mvs_image_format;
 
 /* storage dtype of the private volumes (accumulation is always fp32) */
 typedef enum mvs_dtype { MVS_F32 = 0, MVS_F16 = 1, MVS_BF16 = 2 } mvs_dtype;
@@ -199,6 +213,14 @@ int mvs_forward_images(const float* imgs, const float* proj, const float* depth_
                        const void* feature_blob, const void* weights_blob, float* depth_out,
                        float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
                        int D, int dtype, void* stream);
+/* The same two entry points with the images in any mvs_image_format (ABI 2).  Replaces, for uint8 input, the host-side
+ * float conversion of datasets/data_io.py:143 + the 4x larger host-to-device copy (eval.py:358 `tocuda`). */
+int mvs_feature_net_fmt(const void* imgs, int image_format, const void* feature_blob, float* feats_out,
+                        void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream);
+int mvs_forward_images_fmt(const void* imgs, int image_format, const float* proj, const float* depth_values,
+                           const void* feature_blob, const void* weights_blob, float* depth_out,
+                           float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                           int D, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ def dtype_code(dtype) -> int:
         raise ValueError(f"unsupported storage dtype {dtype}")
     return DTYPE_CODES[str(dtype)]
 NUM_LAYERS = 11
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/mvs_abi.h declares
 SYMBOLS = (
@@ -46,7 +46,11 @@ SYMBOLS = (
     "mvs_filter_compose", "mvs_filter_depth",
     "mvs_query_feature_blob", "mvs_pack_feature_weights", "mvs_query_feature_workspace",
     "mvs_feature_layer", "mvs_feature_net", "mvs_query_forward_workspace", "mvs_forward_images",
+    "mvs_feature_net_fmt", "mvs_forward_images_fmt",
 )
+
+# mvs_image_format (include/mvs_abi.h)
+MVS_IMG_F32_CHW, MVS_IMG_U8_CHW, MVS_IMG_U8_HWC = 0, 1, 2
 
 _lock = threading.Lock()
 _lib = None
@@ -104,6 +108,9 @@ def load():
         lib.mvs_query_forward_workspace.argtypes = [_i, _i, _i, _i, _i, ctypes.POINTER(_sz)]
         lib.mvs_forward_images.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _i, _i, _i, _i, _i, _vp]
+        lib.mvs_feature_net_fmt.argtypes = [_vp, _i, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]
+        lib.mvs_forward_images_fmt.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                               _i, _i, _i, _i, _i, _vp]
         lib.mvs_filter_compose.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]
         _d = ctypes.c_double
         lib.mvs_filter_depth.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
@@ -438,35 +445,54 @@ def feature_layer(layer, x, fblob):
     return y
 
 
-def feature_net(imgs, fblob, workspace=None):
-    """FeatureNet.forward on the GPU: imgs [N,3,H,W] fp32 -> [N,32,H/4,W/4] fp32 (NCHW)."""
+def _image_arg(imgs, what):
+    """Device images in one of the ABI's pixel formats -> (tensor, mvs_image_format, N, H, W):
+    float32 [N,3,H,W]; uint8 [N,3,H,W]; uint8 [N,H,W,3] (as PIL yields a decoded image).  The uint8 forms are
+    divided by 255 inside FeatureNet's first kernel -- the reference's host-side conversion
+    (datasets/data_io.py:143), bit for bit -- so the caller copies a quarter of the bytes."""
+    if not isinstance(imgs, torch.Tensor) or not imgs.is_cuda:
+        raise RuntimeError(f"{what}: images must be a CUDA(ROCm) tensor")
+    if imgs.dim() != 4:
+        raise RuntimeError(f"{what} wants [N,3,H,W] (float32 / uint8) or [N,H,W,3] (uint8) images, got {tuple(imgs.shape)}")
+    if imgs.dtype == torch.uint8:
+        imgs = imgs.contiguous()
+        if imgs.shape[1] == 3:
+            return imgs, MVS_IMG_U8_CHW, imgs.shape[0], imgs.shape[2], imgs.shape[3]
+        if imgs.shape[3] == 3:
+            return imgs, MVS_IMG_U8_HWC, imgs.shape[0], imgs.shape[1], imgs.shape[2]
+        raise RuntimeError(f"{what}: uint8 images must be [N,3,H,W] or [N,H,W,3], got {tuple(imgs.shape)}")
     imgs = _dev_f32(imgs, "imgs")
-    if imgs.dim() != 4 or imgs.shape[1] != 3:
-        raise RuntimeError(f"feature_net wants [N,3,H,W] images, got {tuple(imgs.shape)}")
-    N, _, H, W = imgs.shape
+    if imgs.shape[1] != 3:
+        raise RuntimeError(f"{what} wants [N,3,H,W] images, got {tuple(imgs.shape)}")
+    return imgs, MVS_IMG_F32_CHW, imgs.shape[0], imgs.shape[2], imgs.shape[3]
+
+
+def feature_net(imgs, fblob, workspace=None):
+    """FeatureNet.forward on the GPU: imgs [N,3,H,W] fp32 (or uint8, see _image_arg) -> [N,32,H/4,W/4] fp32 (NCHW)."""
+    imgs, fmt, N, H, W = _image_arg(imgs, "feature_net")
     nbytes = query_feature_workspace(N, H, W)
     if workspace is None:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=imgs.device)
     h4, w4 = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
     out = torch.empty((N, 32, h4, w4), dtype=torch.float32, device=imgs.device)
-    check(load().mvs_feature_net(imgs.data_ptr(), fblob.data_ptr(), out.data_ptr(), workspace.data_ptr(),
-                                 workspace.numel(), N, H, W, _stream(imgs.device)))
+    check(load().mvs_feature_net_fmt(imgs.data_ptr(), fmt, fblob.data_ptr(), out.data_ptr(), workspace.data_ptr(),
+                                     workspace.numel(), N, H, W, _stream(imgs.device)))
     return out
 
 
 def forward_images(imgs, proj, depth_values, fblob, blob, workspace, depth_out, conf_out, dtype=MVS_F32):
-    """MVSNet.forward of one batch item from images: imgs [N,3,H,W], proj [N,4,4], depth_values [D]."""
-    imgs = _dev_f32(imgs, "imgs")
+    """MVSNet.forward of one batch item from images: imgs [N,3,H,W] fp32 (or uint8, see _image_arg), proj [N,4,4],
+    depth_values [D]."""
+    imgs, fmt, N, H, W = _image_arg(imgs, "forward_images")
     proj = _dev_f32(proj, "proj_matrices")
     depth_values = _dev_f32(depth_values, "depth_values")
-    N, c, H, W = imgs.shape
-    if c != 3 or tuple(proj.shape) != (N, 4, 4):
+    if tuple(proj.shape) != (N, 4, 4):
         raise RuntimeError(f"forward_images: imgs {tuple(imgs.shape)} / proj {tuple(proj.shape)}")
     D = depth_values.numel()
     if tuple(depth_out.shape) != (H // 4, W // 4) or tuple(conf_out.shape) != (H // 4, W // 4) \
             or not depth_out.is_contiguous() or not conf_out.is_contiguous():
         raise RuntimeError("forward_images: depth_out / conf_out must be contiguous [H/4, W/4] float32")
-    check(load().mvs_forward_images(imgs.data_ptr(), proj.data_ptr(), depth_values.data_ptr(),
-                                    fblob.data_ptr(), blob.data_ptr(), depth_out.data_ptr(),
-                                    conf_out.data_ptr(), workspace.data_ptr(), workspace.numel(),
-                                    N, H, W, D, dtype, _stream(imgs.device)))
+    check(load().mvs_forward_images_fmt(imgs.data_ptr(), fmt, proj.data_ptr(), depth_values.data_ptr(),
+                                        fblob.data_ptr(), blob.data_ptr(), depth_out.data_ptr(),
+                                        conf_out.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                        N, H, W, D, dtype, _stream(imgs.device)))

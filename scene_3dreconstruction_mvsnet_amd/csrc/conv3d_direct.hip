@@ -464,11 +464,13 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
             const char* e = getenv("MVS_CONV0_WINO");
             return !(e && e[0] == '0');
         }();
-        // MVS_CONV0_SPLIT=1: the same F(4,3) scheme with every operand split into three bf16 pieces, six cross
-        // products per fp32 product on the bf16 matrix cores, fp32 accumulation (conv0_split.hip; fp32 volumes only)
+        // fp32 volumes: the same F(4,3) scheme with every operand split into three bf16 pieces, six cross products per
+        // fp32 product on the bf16 matrix cores, fp32 accumulation (conv0_split.hip: fp32-equivalent arithmetic -- the
+        // per-layer bounds of the fp32 kernel hold unchanged -- at 0.28 instead of 0.36 ms).  MVS_CONV0_SPLIT=0: the
+        // fp32-MFMA kernel below; =2: the split kernel's first form (one tile per block)
         static const bool split = [] {
             const char* e = getenv("MVS_CONV0_SPLIT");
-            return e && e[0] == '1';
+            return !(e && e[0] == '0');
         }();
         if (wino && Di % 4 == 0 && (size_t)Di * Hi * Wi * 32 < ((size_t)1 << 31)) {
             if (split && dtype == MVS_F32)

@@ -210,8 +210,12 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
 // straight into conv1's LDS A-tile (zero where the pixel lies outside the image: conv1 pads
 // conv0's OUTPUT with zeros), then runs conv1 on the MFMA as fconv_mfma_kernel does.
 // ---------------------------------------------------------------------------------------------
+// FMT: pixel format of `img` -- 0 = fp32 [N][3][H][W] (the reference's tensor); 1 = uint8 [N][3][H][W]; 2 = uint8
+// [N][H][W][3] (as PIL yields a decoded image).  The uint8 forms are divided by 255 here with an IEEE division: the
+// value the reference's loader produces on the host (np.array(img, float32) / 255., datasets/data_io.py:143), bit for bit.
+template <int FMT>
 __global__ __launch_bounds__(256) void fconv01_fused_kernel(
-    const float* __restrict__ img,   // [N][3][H][W]
+    const void* __restrict__ img_v,  // [N][3][H][W] fp32 / uint8, or [N][H][W][3] uint8
     const float* __restrict__ w0,    // [27][8] folded conv0 weights, k = (ci*3+ky)*3+kx ; then bias [8]
     const float* __restrict__ bp,    // conv1 panel [1][1][5][64][4]
     const float* __restrict__ bias,  // conv1 bias
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(256) void fconv01_fused_kernel(
     const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, n = blockIdx.y;
     const int ox0 = bx * 32, oy0 = by * 8;
     const size_t HW = (size_t)H * W;
-    const float* im = img + (size_t)n * 3 * HW;
+    const float* im = static_cast<const float*>(img_v) + (size_t)n * 3 * HW;
+    const unsigned char* im8 = static_cast<const unsigned char*>(img_v) + (size_t)n * 3 * HW;
 
     f32x4 breg[G::KS];
     {
@@ -243,7 +248,11 @@ __global__ __launch_bounds__(256) void fconv01_fused_kernel(
         const int iy = rem / IX, ix = rem - iy * IX;
         const int gy = oy0 - 2 + iy, gx = ox0 - 2 + ix;
         float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = im[c * HW + (size_t)gy * W + gx];
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if constexpr (FMT == 0) v = im[c * HW + (size_t)gy * W + gx];
+            else if constexpr (FMT == 1) v = __fdiv_rn((float)im8[c * HW + (size_t)gy * W + gx], 255.0f);
+            else v = __fdiv_rn((float)im8[((size_t)gy * W + gx) * 3 + c], 255.0f);
+        }
         itile[(c * IY + iy) * IXP + ix] = v;
     }
     __syncthreads();
@@ -342,13 +351,18 @@ __global__ __launch_bounds__(256) void fconv01_fused_kernel(
     }
 }
 
-int launch_feature_conv01(const float* imgs, float* y, const float* blob, int N, int H, int W, hipStream_t s) {
+int launch_feature_conv01(const void* imgs, int fmt, float* y, const float* blob, int N, int H, int W, hipStream_t s) {
     const FeatBlob L = feat_blob_layout();
     if ((size_t)N * H * W * 8 >= ((size_t)1 << 31))
         return fail(MVS_ERR_BAD_SHAPE, "feature_net: activation plane exceeds 31-bit offsets");
     dim3 grid(((W + 31) / 32) * ((H + 7) / 8), N);
-    fconv01_fused_kernel<<<grid, 256, 0, s>>>(imgs, blob + L.l0_direct_off, blob + L.panel_off[1],
-                                               blob + L.bias_off[1], y, N, H, W);
+    const float *w0 = blob + L.l0_direct_off, *bp = blob + L.panel_off[1], *b1 = blob + L.bias_off[1];
+    switch (fmt) {
+        case MVS_IMG_F32_CHW: fconv01_fused_kernel<0><<<grid, 256, 0, s>>>(imgs, w0, bp, b1, y, N, H, W); break;
+        case MVS_IMG_U8_CHW: fconv01_fused_kernel<1><<<grid, 256, 0, s>>>(imgs, w0, bp, b1, y, N, H, W); break;
+        case MVS_IMG_U8_HWC: fconv01_fused_kernel<2><<<grid, 256, 0, s>>>(imgs, w0, bp, b1, y, N, H, W); break;
+        default: return fail(MVS_ERR_BAD_DTYPE, "feature_net: unknown image format %d", fmt);
+    }
     return check_hip(hipGetLastError(), "fconv01_fused launch");
 }
 
@@ -385,7 +399,7 @@ int launch_feature_layer(int l, const float* x, float* y, const float* blob, int
 }
 
 // images [N][3][H][W] -> C8-planar features [4][N][H/4][W/4][8]; bufA / bufB hold N*8*H*W floats each
-int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8, float* bufA, float* bufB,
+int launch_feature_net_c8(const void* imgs, int fmt, const float* blob, float* feats_c8, float* bufA, float* bufB,
                           int N, int H, int W, hipStream_t s) {
     const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1, H4 = (H2 - 1) / 2 + 1, W4 = (W2 - 1) / 2 + 1;
     int st;
@@ -394,9 +408,11 @@ int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8,
         return e && e[0] == '1';
     }();
     if (split01) {
-        if ((st = launch_feature_layer(0, imgs, bufA, blob, N, H, W, s))) return st;
+        if (fmt != MVS_IMG_F32_CHW)
+            return fail(MVS_ERR_BAD_DTYPE, "MVS_FEAT_SPLIT01=1 (cross-check kernels) takes fp32 images only");
+        if ((st = launch_feature_layer(0, static_cast<const float*>(imgs), bufA, blob, N, H, W, s))) return st;
         if ((st = launch_feature_layer(1, bufA, bufB, blob, N, H, W, s))) return st;
-    } else if ((st = launch_feature_conv01(imgs, bufB, blob, N, H, W, s))) {
+    } else if ((st = launch_feature_conv01(imgs, fmt, bufB, blob, N, H, W, s))) {
         return st;
     }
     if ((st = launch_feature_layer(2, bufB, bufA, blob, N, H, W, s))) return st;

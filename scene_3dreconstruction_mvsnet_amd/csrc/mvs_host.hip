@@ -370,8 +370,15 @@ int mvs_feature_layer(int layer, const float* x, float* y, const void* feature_b
 
 int mvs_feature_net(const float* imgs, const void* feature_blob, float* feats_out, void* workspace,
                     size_t workspace_bytes, int N, int H, int W, void* stream) {
+    return mvs_feature_net_fmt(imgs, MVS_IMG_F32_CHW, feature_blob, feats_out, workspace, workspace_bytes, N, H, W, stream);
+}
+
+int mvs_feature_net_fmt(const void* imgs, int image_format, const void* feature_blob, float* feats_out, void* workspace,
+                        size_t workspace_bytes, int N, int H, int W, void* stream) {
     if (!imgs || !feature_blob || !feats_out || !workspace)
         return fail(MVS_ERR_NULL, "mvs_feature_net: NULL argument");
+    if (image_format < MVS_IMG_F32_CHW || image_format > MVS_IMG_U8_HWC)
+        return fail(MVS_ERR_BAD_DTYPE, "mvs_feature_net: unknown image format %d", image_format);
     if (int st = check_image_dims(N, H, W)) return st;
     const FeatWorkspace F = feat_workspace_layout(N, H, W);
     if (workspace_bytes < F.total)
@@ -381,7 +388,7 @@ int mvs_feature_net(const float* imgs, const void* feature_blob, float* feats_ou
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* c8 = reinterpret_cast<float*>(ws + F.c8);
-    if (int st = launch_feature_net_c8(imgs, static_cast<const float*>(feature_blob), c8,
+    if (int st = launch_feature_net_c8(imgs, image_format, static_cast<const float*>(feature_blob), c8,
                                        reinterpret_cast<float*>(ws + F.bufA),
                                        reinterpret_cast<float*>(ws + F.bufB), N, H, W, s))
         return st;
@@ -401,6 +408,16 @@ int mvs_forward_images(const float* imgs, const float* proj, const float* depth_
                        const void* feature_blob, const void* weights_blob, float* depth_out,
                        float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
                        int D, int dtype, void* stream) {
+    return mvs_forward_images_fmt(imgs, MVS_IMG_F32_CHW, proj, depth_values, feature_blob, weights_blob, depth_out,
+                                  conf_out, workspace, workspace_bytes, N, H, W, D, dtype, stream);
+}
+
+int mvs_forward_images_fmt(const void* imgs, int image_format, const float* proj, const float* depth_values,
+                           const void* feature_blob, const void* weights_blob, float* depth_out,
+                           float* conf_out, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                           int D, int dtype, void* stream) {
+    if (image_format < MVS_IMG_F32_CHW || image_format > MVS_IMG_U8_HWC)
+        return fail(MVS_ERR_BAD_DTYPE, "mvs_forward_images: unknown image format %d", image_format);
     if (!imgs || !proj || !depth_values || !feature_blob || !weights_blob || !depth_out || !conf_out ||
         !workspace)
         return fail(MVS_ERR_NULL, "mvs_forward_images: NULL argument");
@@ -424,7 +441,8 @@ int mvs_forward_images(const float* imgs, const float* proj, const float* depth_
     // the last layer writes the path's C8 feature slot directly (fp32), or a scratch copy that is
     // then narrowed into it for the 16-bit gather
     float* c8 = narrow ? reinterpret_cast<float*>(fws + F.c8) : feats_t;
-    if (int st = launch_feature_net_c8(imgs, static_cast<const float*>(feature_blob), c8, bufA, bufB, N, H, W, s))
+    if (int st = launch_feature_net_c8(imgs, image_format, static_cast<const float*>(feature_blob), c8, bufA, bufB, N, H,
+                                       W, s))
         return st;
     if (narrow)
         if (int st = launch_narrow_features(c8, feats_t, (size_t)N * kC * h * w, dtype, s)) return st;

@@ -172,8 +172,8 @@ inline FeatWorkspace feat_workspace_layout(int N, int H, int W) {
 bool feat16_gather();
 int launch_feature_layer(int l, const float* x, float* y, const float* blob, int N, int Hi, int Wi,
                          hipStream_t s);
-int launch_feature_net_c8(const float* imgs, const float* blob, float* feats_c8, float* bufA, float* bufB,
-                          int N, int H, int W, hipStream_t s);
+int launch_feature_net_c8(const void* imgs, int fmt, const float* blob, float* feats_c8, float* bufA, float* bufB,
+                          int N, int H, int W, hipStream_t s);   // fmt: mvs_image_format
 int launch_c8_to_nchw(const float* in, float* out, int N, int C, int h, int w, hipStream_t s);
 int launch_narrow_features(const float* in, void* out, size_t n, int dtype, hipStream_t s);
 void pack_fconv_weights(const float* w, int cin, int cout, int k, float* bp);

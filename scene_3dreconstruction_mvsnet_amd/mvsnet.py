@@ -85,6 +85,8 @@ class RefineNet(nn.Module):
 
 
 class MVSNet(nn.Module):
+    ACCEPTS_UINT8_IMAGES = True   # forward() also takes uint8 [B,N,3,H,W] / [B,N,H,W,3] images (see forward)
+
     def __init__(self, refine=True, debug=0):
         super().__init__()
         self.refine = refine
@@ -209,15 +211,21 @@ class MVSNet(nn.Module):
                                       "(F.cat at models/mvsnet.py:85); every working caller passes "
                                       "refine=False (eval.py:308)")
         device = imgs.device
-        B, N, _, H, W = imgs.shape
+        # uint8 images -- [B,N,3,H,W], or [B,N,H,W,3] as a decoder yields them -- are the reference loader's pixels
+        # before `np.array(img, float32) / 255.` (datasets/data_io.py:143); the HIP FeatureNet divides on the device
+        u8_hwc = imgs.dtype == torch.uint8 and imgs.shape[2] != 3 and imgs.shape[-1] == 3
+        if u8_hwc:
+            B, N, H, W, _ = imgs.shape
+        else:
+            B, N, _, H, W = imgs.shape
         D = depth_values.shape[1]
         if self.feature_impl not in ("hip", "torch"):
             raise RuntimeError(f"feature_impl must be 'hip' or 'torch', got {self.feature_impl!r}")
         if self.feature_impl == "hip":
-            if imgs.shape[2] != 3 or H % 32 or W % 32:
+            if (not u8_hwc and imgs.shape[2] != 3) or H % 32 or W % 32:
                 raise RuntimeError(f"imgs must be [B,N,3,H,W] with H, W multiples of 32, got {tuple(imgs.shape)}")
             with torch.cuda.device(device), torch.no_grad():
-                imgs_f = _lib._dev_f32(imgs.to(torch.float32), "imgs")
+                imgs_f = imgs.contiguous() if imgs.dtype == torch.uint8 else _lib._dev_f32(imgs.to(torch.float32), "imgs")
                 proj = _lib._dev_f32(proj_matrices.to(device), "proj_matrices")
                 dv = _lib._dev_f32(depth_values.to(device), "depth_values")
                 blob, fblob = self._weights_blob(device), self._feature_blob(device)
@@ -230,6 +238,8 @@ class MVSNet(nn.Module):
                     _lib.forward_images(imgs_f[b], proj[b], dv[b], fblob, blob, ws, depth[b], conf[b], dtype=dt)
             return {"depth": depth, "photometric_confidence": conf}
         with torch.cuda.device(device), torch.no_grad():
+            if imgs.dtype == torch.uint8:   # the torch FeatureNet path: the loader's conversion, on the device
+                imgs = (imgs.permute(0, 1, 4, 2, 3) if u8_hwc else imgs).to(torch.float32) / 255.0
             # step 1. feature extraction (reference mvsnet.py:125), all B*N images in one call
             feats = self.feature(imgs.reshape(B * N, imgs.shape[2], H, W).to(torch.float32))
             C, h, w = feats.shape[1], feats.shape[2], feats.shape[3]

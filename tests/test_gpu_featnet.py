@@ -109,6 +109,38 @@ def test_hip_and_torch_feature_paths_agree(storage, weights):
     assert rel_l1(da, db) < (2e-5 if storage == "f32" else 2e-3)
 
 
+def test_uint8_images_are_bit_identical_to_the_loaders_float_conversion(weights, fblob):
+    """The reference's loader turns a decoded 8-bit image into `np.array(img, dtype=np.float32) / 255.`
+    (datasets/data_io.py:143) on the host and the eval script copies the floats (eval.py:358).  Handing the uint8
+    pixels over instead -- [N,3,H,W], or [N,H,W,3] as the decoder yields them -- and dividing inside FeatureNet's
+    first kernel must give the SAME BITS: features and maps."""
+    g = np.random.default_rng(5)
+    N, H, W = 3, 64, 96
+    u8_hwc = g.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)
+    u8_hwc[0, 0, :4, 0] = (0, 1, 254, 255)
+    as_loader = u8_hwc.astype(np.float32) / 255.            # the reference's arithmetic, on the host
+    f_chw = np.ascontiguousarray(as_loader.transpose(0, 3, 1, 2))
+    u8_chw = np.ascontiguousarray(u8_hwc.transpose(0, 3, 1, 2))
+    want = _lib.feature_net(torch.from_numpy(f_chw).to(DEV), fblob)
+    for variant in (u8_chw, u8_hwc):
+        got = _lib.feature_net(torch.from_numpy(variant).to(DEV), fblob)
+        assert got.shape == want.shape and torch.equal(got, want)
+    # the drop-in's forward: same maps from the three forms, for B = 2
+    m = _model(weights, "hip")
+    proj = torch.from_numpy(load_fixture("small")["proj_matrices"][:1, :N]).to(DEV).repeat(2, 1, 1, 1)
+    dv = torch.from_numpy(load_fixture("small")["depth_values"][:1]).to(DEV).repeat(2, 1)
+    f5 = torch.from_numpy(np.stack([f_chw, f_chw[::-1].copy()])).to(DEV)
+    o_f = m(f5, proj, dv)
+    for variant in (np.stack([u8_chw, u8_chw[::-1].copy()]), np.stack([u8_hwc, u8_hwc[::-1].copy()])):
+        o_u = m(torch.from_numpy(variant).to(DEV), proj, dv)
+        assert torch.equal(o_u["depth"], o_f["depth"])
+        assert torch.equal(o_u["photometric_confidence"], o_f["photometric_confidence"])
+    # and the PyTorch FeatureNet path accepts them too (same conversion on the device)
+    t = _model(weights, "torch")
+    assert rel_l1(t(torch.from_numpy(np.stack([u8_hwc, u8_hwc[::-1].copy()])).to(DEV), proj, dv)["depth"].cpu().numpy(),
+                  o_f["depth"].cpu().numpy()) < 2e-5
+
+
 def test_forward_rejects_bad_image_shapes(weights):
     m = _model(weights, "hip")
     with pytest.raises(RuntimeError, match="multiples of 32"):

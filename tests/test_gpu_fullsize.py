@@ -167,6 +167,20 @@ def test_winograd_layers_on_a_heavy_tailed_nonnegative_volume(cfg2, layer, shape
     assert rel_l1(got, want) < 5e-6
 
 
+@pytest.mark.parametrize("split", ["0", "2"])
+def test_cfg2_conv0_kernel_variants_match_oracle(split):
+    """conv0's other kernels at FULL size with the per-layer bounds of test_cfg2_every_layer_matches_oracle[0]: the
+    fp32-MFMA Winograd kernel (MVS_CONV0_SPLIT=0; the default until round 4) and the first form of the split-operand
+    kernel (=2).  Selection is read once per process -> child process (tests/conv0_check.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "conv0_check.py")], env=dict(os.environ, MVS_CONV0_SPLIT=split),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_cfg2_layer_test_would_catch_a_dropped_tap(cfg2):
     """The sensitivity the per-layer comparison buys: zero ONE of conv4's 27x32x32 taps in the
     oracle and the per-layer metric moves far beyond its bound, while end-to-end depth moves 1e-5."""

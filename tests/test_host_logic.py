@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.load().mvs_abi_version() == 1
+    assert _lib.load().mvs_abi_version() == 2
 
 
 def test_query_workspace_and_shape_errors():
@@ -483,7 +483,13 @@ def test_bench_roofline_fractions_never_exceed_one():
     bench = _bench()
     N, D, h, w = 5, 192, 128, 160
     costs = bench.stage_costs(N, D, h, w, 4)
-    ex = bench.executed_costs(costs, "f32", N, D, h, w, env={})
+    exs = bench.executed_costs(costs, "f32", N, D, h, w, env={})      # default: conv0 with split bf16 operands
+    assert exs["conv0"]["flops"] == costs["conv0"]["flops"] * 4 and exs["conv0"]["mfma_peak"] == bench.MFMA_16BIT_PEAK_TFLOPS
+    ents = bench.stage_entry(0.276, costs["conv0"], exs["conv0"], bench.mfma_peak_tflops("f32"))
+    assert ents["bound"] == "mfma" and 0.25 < ents["frac"] < 0.40 and ents["frac_algorithmic"] > 1.0 and "split" in ents["arith"]
+    rs = bench.roofline_entry("conv0", 0.276, costs["conv0"], exs["conv0"], bench.mfma_peak_tflops("f32"))
+    assert rs["peak"] == bench.MFMA_16BIT_PEAK_TFLOPS and rs["frac"] <= 1.0 and rs["algorithmic_ratio"] > 1.0
+    ex = bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_SPLIT": "0"})   # the fp32-MFMA Winograd kernel
     assert ex["conv0"]["flops"] == costs["conv0"]["flops"] * 0.5
     assert abs(ex["conv2"]["flops"] / costs["conv2"]["flops"] - 20 / 27) < 1e-12
     assert ex["conv1"] == costs["conv1"] and ex["conv0"]["bytes"] == costs["conv0"]["bytes"]

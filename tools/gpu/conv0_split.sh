@@ -6,6 +6,7 @@ export MVS_CONV0_SPLIT=1
 python tests/layer_check.py 16 24 40 > gpurun_out/split_layer_check.log 2>&1; echo "layer_check rc=$?"; tail -3 gpurun_out/split_layer_check.log
 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k "every_layer_matches_oracle or heavy_tailed or cost_volume_and_maps or reference_fixture" -s > gpurun_out/split_fullsize.log 2>&1; echo "fullsize rc=$?"; grep -E "heavy-tailed|passed|failed|Error|assert" gpurun_out/split_fullsize.log | head -20
 for i in 1 2; do
+MVS_CONV0_SPLIT=2 python tools/time_stage.py conv0 200
 MVS_CONV0_SPLIT=0 python tools/time_stage.py conv0 200
 MVS_CONV0_SPLIT=1 python tools/time_stage.py conv0 200
 done
