@@ -106,7 +106,14 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
                     ex["conv0"]["flops"] = costs["conv0"]["flops"] * 4.0
                     ex["conv0"]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
                     ex["conv0"]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"
-            if env.get("MVS_CONV_WINO") != "0":
+            if env.get("MVS_SPLIT_LAYERS") != "0":
+                # conv2 .. conv4 (.. conv6 with MVS_SPLIT_LAYERS=2): split operands on the bf16 matrix cores, six cross
+                # products per product, 27 taps padded to 28 (csrc/conv3d_mfma16.hip convgs)
+                for n in ("conv2", "conv3", "conv4") + (("conv5", "conv6") if env.get("MVS_SPLIT_LAYERS") == "2" else ()):
+                    ex[n]["flops"] = costs[n]["flops"] * 6.0 * 28.0 / 27.0
+                    ex[n]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
+                    ex[n]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"
+            elif env.get("MVS_CONV_WINO") != "0":
                 for n in ("conv2", "conv4"):
                     ex[n]["flops"] = costs[n]["flops"] * 20.0 / 27.0
     else:
@@ -714,7 +721,9 @@ def main(argv=None):
             "warmup": Wm, "effective_warmup_steps": res["effective_warmup"],
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (conv0: 3xbf16 split operands, fp32 accumulate)" if conv0_split else "f32") if storage == "f32" else (
+            "dtype": ("f32 (conv0, conv2-4: 3xbf16 split operands on the bf16 matrix cores, fp32 accumulate)"
+                      if conv0_split and os.environ.get("MVS_SPLIT_LAYERS") != "0" else
+                      "f32 (conv0: 3xbf16 split operands, fp32 accumulate)" if conv0_split else "f32") if storage == "f32" else (
                 f"{storage} storage, f32 MFMA arithmetic" if os.environ.get("MVS_MFMA16") == "0"
                 else f"{storage} storage and MFMA operands, f32 accumulation"),
             "data": "synthetic",

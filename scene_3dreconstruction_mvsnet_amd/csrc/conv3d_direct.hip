@@ -479,6 +479,14 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         }
         return launch_conv0_mfma(x, y, blob + L.c0q_off, blob + L.b_off[0], Di, Hi, Wi, dtype, s);
     }
+    // fp32 volumes: the level-1 .. 3 layers on the bf16 matrix cores with split operands (conv3d_mfma16.hip, round 4)
+    // unless MVS_SPLIT_LAYERS=0 keeps the fp32-MFMA kernels below
+    static const bool split_layers = [] {
+        const char* e = getenv("MVS_SPLIT_LAYERS");
+        return !(e && e[0] == '0');
+    }();
+    if (split_layers && dtype == MVS_F32 && split_layer_covers(layer))
+        return launch_layer_split(layer, x, skip, y, blob + L.s16_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
     if (layer == 2 || layer == 4) {
         // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv_winograd.hip) unless
         // MVS_CONV_WINO=0.  conv6 (64 -> 64 on 7,680 voxels) stays direct: with two-plane tiles it has

@@ -1045,6 +1045,217 @@ int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, con
     return fail(MVS_ERR_BAD_DTYPE, "mfma16 kernels need fp16 or bf16 storage (dtype %d)", dtype);
 }
 
+// =============================================================================================
+// SPLIT-OPERAND kernels for fp32 volumes (round 4): the tile kernels above with every fp32 operand written as the sum
+// of three bf16 numbers (a = a1 + a2 + a3, RNE, exact residuals) and the fp32 product evaluated as the six leading
+// cross products a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the
+// dropped terms are <= 2^-26 of the product (csrc/conv0_split.hip has the argument), the per-layer bounds of the
+// fp32-MFMA kernels hold unchanged, and six bf16 MFMAs cost 6/16 of the fp32 MFMA time they replace.  Inputs and
+// outputs are the fp32 C8-planar volumes; a staged voxel (8 channels, two 16-byte loads) is split once, on its way
+// into LDS, into three 16-byte bf16 fragments (three tiles); the weights are split on the host (three panels in the
+// layout of the 16-bit kernels: pack_split_panels).
+//   convgs   : conv2 .. conv4 by default, conv5 / conv6 with MVS_SPLIT_LAYERS=2 (the tile scheme of convg16)
+// =============================================================================================
+typedef float g_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ g_f32x2 gs_stage(const g_f32x2 a, unsigned& packed) {   // packed = bf16x2(a) RNE; returns a - packed
+    const g_bf16x2 h = __builtin_convertvector(a, g_bf16x2);
+    packed = __builtin_bit_cast(unsigned, h);
+    const g_f32x2 w = {__uint_as_float(packed << 16), __uint_as_float(packed & 0xFFFF0000u)};
+    return a - w;
+}
+// 8 fp32 channels of one voxel -> three 16-byte bf16 fragments
+__device__ __forceinline__ void gs_split8(const f32x4 lo, const f32x4 hi, u32x4& p1, u32x4& p2, u32x4& p3) {
+    const g_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b;
+        const g_f32x2 r1 = gs_stage(v[j], a);
+        const g_f32x2 r2 = gs_stage(r1, b);
+        p1[j] = a;
+        p2[j] = b;
+        p3[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, g_bf16x2));
+    }
+}
+__device__ __forceinline__ f32x4 gs_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void convgs_mfma_kernel(
+    const float* __restrict__ x,              // [CIN/8][Di][Hi][Wi][8] fp32
+    const unsigned short* __restrict__ bp,    // [3 pieces][NCH][NT][7][64][8] bf16
+    const float* __restrict__ bias,           // [COUT]
+    float* __restrict__ y,                    // [COUT/8][Do][Ho][Wo][8] fp32
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+    using G = ConvG16<CIN, COUT, S, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[3 * G::TILE_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NT, mg = wave / G::NT;
+    const int nbx = (Wo + 8 * BX - 1) / (8 * BX), nby = (Ho + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ox0 = bx * 8 * BX, oy0 = by * 2 * BY, oz0 = bz * BZ;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = (size_t)Do * Ho * Wo;
+    constexpr size_t PANEL = (size_t)G::NCH * G::NT * G::KS * 64;   // u32x4 fragments per piece
+
+    // staging: piece p = tid + i * 256 = one voxel (8 channels) of the halo tile; threads beyond the tile shadow its
+    // last voxel (no branch in the staging code)
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int v = min(tid + i * 256, G::NPIECE - 1);
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = ((hz * G::HY + hy) * G::HXP + hx) * G::VS;
+    }
+
+    // A fragment: lane (r = lane&15 -> voxel (ry, rx) of the M-tile, g = lane>>4 -> tap 4ks+g)
+    const int r = lane & 15, g = lane >> 4;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = (((tz * S) * G::HY + (2 * ty + ry) * S) * G::HXP + (8 * tx + rx) * S) * G::VS;
+    }
+    int koff[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+        koff[ks] = g == 0 ? G::tap_off(4 * ks) : g == 1 ? G::tap_off(4 * ks + 1)
+                 : g == 2 ? G::tap_off(4 * ks + 2) : G::tap_off(4 * ks + 3);
+
+    f32x4 acc[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 breg[3][G::KS];
+    f32x4 stg[G::PPT][2];
+
+    auto load_b = [&](int c) {
+        const u32x4* bsrc = reinterpret_cast<const u32x4*>(bp) + ((size_t)(c * G::NT + nt) * G::KS) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) breg[q][ks] = bsrc[q * PANEL + ks * 64];
+    };
+    auto load_a = [&](int c) {
+        const float* plane = x + (size_t)c * Vin * 8;
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) {
+            stg[i][0] = *reinterpret_cast<const f32x4*>(plane + goff[i]);
+            stg[i][1] = *reinterpret_cast<const f32x4*>(plane + goff[i] + 4);
+        }
+    };
+    auto store_a = [&]() {
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) {
+            const bool in = (inside >> i) & 1u;
+            u32x4 p1, p2, p3;
+            gs_split8(in ? stg[i][0] : z4, in ? stg[i][1] : z4, p1, p2, p3);
+            *reinterpret_cast<u32x4*>(tile + loff[i]) = p1;
+            *reinterpret_cast<u32x4*>(tile + G::TILE_ELEMS + loff[i]) = p2;
+            *reinterpret_cast<u32x4*>(tile + 2 * G::TILE_ELEMS + loff[i]) = p3;
+        }
+    };
+
+    load_b(0);
+    load_a(0);
+    store_a();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) load_a(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) {
+                const unsigned short* ap = tile + abase[i] + koff[ks];
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(ap);
+                const u32x4 a2 = *reinterpret_cast<const u32x4*>(ap + G::TILE_ELEMS);
+                const u32x4 a3 = *reinterpret_cast<const u32x4*>(ap + 2 * G::TILE_ELEMS);
+                acc[i] = gs_mfma(a3, breg[0][ks], acc[i]);   // the small terms first
+                acc[i] = gs_mfma(a1, breg[2][ks], acc[i]);
+                acc[i] = gs_mfma(a2, breg[1][ks], acc[i]);
+                acc[i] = gs_mfma(a2, breg[0][ks], acc[i]);
+                acc[i] = gs_mfma(a1, breg[1][ks], acc[i]);
+                acc[i] = gs_mfma(a1, breg[0][ks], acc[i]);
+            }
+        }
+        if (c + 1 < G::NCH) {
+            load_b(c + 1);
+            __syncthreads();
+            store_a();
+            __syncthreads();
+        }
+    }
+
+    const int n = lane & 15, co = 16 * nt + n;
+    const float bv = bias[co];
+    const size_t yplane = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = oz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
+            if (gz < Do && gy < Ho && gx < Wo)
+                y[yplane + (((size_t)gz * Ho + gy) * Wo + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+        }
+    }
+}
+
+template <int CIN, int COUT, int S, int BZ, int BY, int BX>
+static int run_convgs(const void* x, void* y, const unsigned short* bp, const float* bias, int Di, int Hi, int Wi,
+                      hipStream_t s) {
+    const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "convgs_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
+    convgs_mfma_kernel<CIN, COUT, S, BZ, BY, BX><<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
+                                                                    static_cast<float*>(y), Di, Hi, Wi, Do, Ho, Wo);
+    return check_hip(hipGetLastError(), "convgs_mfma launch");
+}
+
+// fp32 volumes, split operands: conv2, conv3, conv4 (measured at cfg2 against the fp32-MFMA kernels: 0.0588 -> 0.0534,
+// 0.0310 -> 0.0276, 0.0396 -> 0.0329 ms).  conv1 keeps its z-marching fp32 kernel (bound by the bytes it moves), conv5 /
+// conv6 their all-K-resident split-K fp32 kernels (0.0176 / 0.0242 against 0.0182 / 0.0289 ms here: on 7,680 voxels the
+// tile kernel's chunk pipeline is the cost, not the matrix pipe); MVS_SPLIT_LAYERS=2 forces all of 2 .. 6 (tests)
+bool split_layer_covers(int layer) {
+    static const bool all = [] {
+        const char* e = getenv("MVS_SPLIT_LAYERS");
+        return e && e[0] == '2';
+    }();
+    return layer >= 2 && layer <= (all ? 6 : 4);
+}
+int launch_layer_split(int layer, const void* x, const void* skip, void* y, const void* panel, const float* bias,
+                       int Di, int Hi, int Wi, hipStream_t s) {
+    const unsigned short* bp = static_cast<const unsigned short*>(panel);
+    (void)skip;
+    switch (layer) {
+        case 2: return run_convgs<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convgs<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 4: return run_convgs<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 5: return run_convgs<32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 6: return run_convgs<64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        default: return fail(MVS_ERR_BAD_SHAPE, "split kernels: layer %d not covered", layer);
+    }
+}
+
 // 16-bit elements of the panel of layer l (0..9)
 size_t mfma16_panel_elems(int layer) {
     const LayerSpec& S = kLayers[layer];
@@ -1059,6 +1270,26 @@ void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out) {
     if (layer == 0) pack_conv0p16_weights(wfold, dt, bp);
     else if (layer <= 6) pack_convg16_weights(wfold, S.cin, S.cout, dt, bp);
     else pack_deconvg16_weights(wfold, S.cin, S.cout, dt, bp);
+}
+
+// the three bf16 pieces of every folded weight, each packed like the bf16 panel of the 16-bit kernels:
+// out = [3 pieces][mfma16_panel_elems(layer)] 16-bit
+void pack_split_panels(int layer, const float* wfold, void* out) {
+    const LayerSpec& S = kLayers[layer];
+    const size_t n = (size_t)27 * S.cin * S.cout, elems = mfma16_panel_elems(layer);
+    float* piece = new float[n];
+    float* rest = new float[n];
+    for (size_t i = 0; i < n; ++i) rest[i] = wfold[i];
+    auto widen = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
+    for (int q = 0; q < 3; ++q) {
+        for (size_t i = 0; i < n; ++i) {
+            piece[i] = widen(to_bits16(rest[i], MVS_BF16));
+            rest[i] -= piece[i];   // exact in fp32
+        }
+        pack_mfma16_panel(layer, piece, MVS_BF16, static_cast<unsigned short*>(out) + (size_t)q * elems);
+    }
+    delete[] piece;
+    delete[] rest;
 }
 
 }  // namespace mvs

@@ -45,6 +45,7 @@ struct BlobLayout {
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv_winograd.hip)
     size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv_winograd.hip)
     size_t c0w43s_off;             // the same weights as three bf16 pieces, Toeplitz panel [4][6][3][3][64][8] (conv0_split.hip)
+    size_t s16_off[10];            // split-operand panels of layers 1..9: three bf16 pieces in the h16 layout (conv3d_mfma16.hip)
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -84,6 +85,12 @@ inline BlobLayout blob_layout() {
     off += (size_t)4 * 6 * 9 * 2 * 2 * 4 * 4;
     L.c0w43s_off = off;
     off += (size_t)4 * 6 * 3 * 3 * 64 * 8 / 2;
+    for (int l = 1; l < 10; ++l) {
+        const size_t elems = l <= 6 ? (size_t)(kLayers[l].cin / 8) * (kLayers[l].cout / 16) * 7 * 64 * 8
+                                    : (size_t)(kLayers[l].cin / 8) * (2 * kLayers[l].cout / 16) * 5 * 64 * 8;
+        L.s16_off[l] = off;
+        off += (3 * elems / 2 + 63) & ~(size_t)63;
+    }
     L.total_floats = off;
     return L;
 }
@@ -264,6 +271,11 @@ bool mfma16_enabled();   // MVS_MFMA16 != 0
 int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, const void* panel,
                         const float* bias, int Di, int Hi, int Wi, int dtype, hipStream_t s);
 void pack_mfma16_panel(int layer, const float* wfold, int dt, void* out);
+// fp32 volumes with split bf16 operands (three pieces, six cross products): the tile kernels of conv3d_mfma16.hip
+bool split_layer_covers(int layer);
+int launch_layer_split(int layer, const void* x, const void* skip, void* y, const void* panel, const float* bias,
+                       int Di, int Hi, int Wi, hipStream_t s);
+void pack_split_panels(int layer, const float* wfold, void* out);
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s);
 int launch_depth_regression(const float* p, const float* dv, float* depth, int D, int h, int w,

@@ -20,13 +20,16 @@ namespace mvs {
 // (one exp per logit, no running rescale).  Three dependent round trips -> one and half the exps moved the kernel
 // from 0.0147 to 0.0142 ms at cfg2 only: it is neither, but 1,280 short blocks of launch / barrier latency.
 // Larger D falls back to the looping form.
-template <int MAXPER>
+// Round 4: PIX / NS are template parameters.  With 16 pixels per block a wave's load touched four 64-byte segments (a
+// quarter of four cache lines each); 32 pixels x 8 slices reads whole 128-byte lines (cfg3: 121 MB of logits at 2.0 ->
+// see DESIGN section 6) and still launches hw / 32 blocks.
+template <int MAXPER, int PIX, int NS>
 __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __restrict__ cost,
                                                               const float* __restrict__ dv,
                                                               float* __restrict__ depth,
                                                               float* __restrict__ conf, int D,
                                                               int hw) {
-    constexpr int PIX = 16, NS = 16;  // pixels per block, depth slices (256 threads)
+    static_assert(PIX * NS == 256, "pixels per block x depth slices = 256 threads");
     __shared__ float s_m[NS][PIX], s_s[NS][PIX], s_d[NS][PIX], s_i[NS][PIX], s_c[NS][PIX];
     __shared__ float s_M[PIX], s_inv[PIX];
     __shared__ int s_idx[PIX];
@@ -161,9 +164,17 @@ __global__ __launch_bounds__(256) void softargmin_conf_loop_kernel(const float* 
 int launch_softargmin(const float* cost, const float* dv, float* depth, float* conf, int D, int h,
                       int w, hipStream_t s) {
     const int hw = h * w;
+    // 32 pixels x 8 slices when that still gives every CU two blocks (>= 512 blocks), else 16 x 16
+    if (hw >= 32 * 512 && D <= 256) {
+        const int per = (D + 7) / 8;
+        if (per <= 16) softargmin_conf_kernel<16, 32, 8><<<(hw + 31) / 32, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+        else if (per <= 24) softargmin_conf_kernel<24, 32, 8><<<(hw + 31) / 32, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+        else softargmin_conf_kernel<32, 32, 8><<<(hw + 31) / 32, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+        return check_hip(hipGetLastError(), "softargmin launch");
+    }
     const int per = (D + 15) / 16;
-    if (per <= 8) softargmin_conf_kernel<8><<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
-    else if (per <= 16) softargmin_conf_kernel<16><<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+    if (per <= 8) softargmin_conf_kernel<8, 16, 16><<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
+    else if (per <= 16) softargmin_conf_kernel<16, 16, 16><<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
     else softargmin_conf_loop_kernel<<<(hw + 15) / 16, 256, 0, s>>>(cost, dv, depth, conf, D, hw);
     return check_hip(hipGetLastError(), "softargmin launch");
 }

@@ -316,6 +316,8 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_WARP_TC": "0"},        # plain gather warp+variance kernel (tap cache off; also the N > 5 path)
     {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
     {"MVS_CONV0_SPLIT": "0"},    # conv0 on the fp32 MFMA (Winograd F(4,3)) instead of split bf16 operands
+    {"MVS_SPLIT_LAYERS": "0"},   # conv2 .. conv4 on the fp32 MFMA (Winograd F(2,3) / generic kernels)
+    {"MVS_SPLIT_LAYERS": "2"},   # conv5 / conv6 on the split-operand tile kernel too
     {"MVS_CONV0_SPLIT": "2"},    # the split-operand conv0 in its first form (one tile per 4-wave block)
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches

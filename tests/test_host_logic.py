@@ -165,6 +165,16 @@ def test_pack_weights_folds_bn_and_relayouts():
         if want != 0.0:
             assert abs(got[1]) <= 2.0 ** -8 * abs(want) and abs(got[2]) <= 2.0 ** -16 * abs(want)
     off += n16 // 2
+    # split-operand panels of layers 1..9: three bf16 pieces, each in the layout of the layer's bf16 panel (h16);
+    # piece 0 IS the bf16 panel (RNE of the folded weights), and the three pieces add up to the fp32 panel value
+    for l in range(1, 10):
+        ci, co = _lib._LAYER_CH[l]
+        elems = (ci // 8) * (co // 16) * 7 * 64 * 8 if l <= 6 else (ci // 8) * (2 * co // 16) * 5 * 64 * 8
+        pcs = blob[off:off + (3 * elems) // 2].view(np.uint16).reshape(3, elems)
+        f = (pcs.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        assert np.all(np.abs(f[1]) <= 2.0 ** -8 * np.abs(f[0]) + 1e-30) and np.all(np.abs(f[2]) <= 2.0 ** -16 * np.abs(f[0]) + 1e-30)
+        assert (f[0] != 0).mean() > 0.5
+        off += ((3 * elems) // 2 + 63) // 64 * 64
     assert off * 4 == _lib.query_weights_blob()
 
 
@@ -491,6 +501,8 @@ def test_bench_roofline_fractions_never_exceed_one():
     assert rs["peak"] == bench.MFMA_16BIT_PEAK_TFLOPS and rs["frac"] <= 1.0 and rs["algorithmic_ratio"] > 1.0
     ex = bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_SPLIT": "0"})   # the fp32-MFMA Winograd kernel
     assert ex["conv0"]["flops"] == costs["conv0"]["flops"] * 0.5
+    assert exs["conv2"]["mfma_peak"] == bench.MFMA_16BIT_PEAK_TFLOPS and abs(exs["conv2"]["flops"] / costs["conv2"]["flops"] - 6 * 28 / 27) < 1e-12
+    ex = bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_SPLIT": "0", "MVS_SPLIT_LAYERS": "0"})
     assert abs(ex["conv2"]["flops"] / costs["conv2"]["flops"] - 20 / 27) < 1e-12
     assert ex["conv1"] == costs["conv1"] and ex["conv0"]["bytes"] == costs["conv0"]["bytes"]
     assert bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_WINO": "0"})["conv0"]["flops"] == costs["conv0"]["flops"]
