@@ -49,16 +49,20 @@ def parse_cam_file(path: str, interval_scale: float = 1.0):
 
 
 def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512, 640), base: int = 32,
-                                cache: "dict | None" = None, cache_size: int = 0):
+                                cache: "dict | None" = None, cache_size: int = 0, image_dtype: str = "float32"):
     """-> (float32 HxWx3 in [0,1], adjusted intrinsics).  `intrinsics` is modified in place too,
-    as the reference does.
+    as the reference does.  image_dtype="uint8": the decoded pixels BEFORE the reference's
+    `np.array(img, dtype=np.float32) / 255.` (datasets/data_io.py:143) -- the drop-in MVSNet divides on the device,
+    bit-identically, and the host-to-device copy is a quarter of the bytes.
 
     `cache` (an insertion-ordered dict used as an LRU of at most `cache_size` entries) keeps the decoded,
     rescaled and cropped pixels per (path, img_res) together with the scale and crop offsets the
     intrinsics are adjusted by: in an eval run every view is decoded as the reference view of one
     sample and again as a source view of several neighbours.  The returned pixel array is then
     shared between samples (read-only use: np.stack copies it into the sample)."""
-    key = (path, tuple(img_res), base)
+    if image_dtype not in ("float32", "uint8"):
+        raise ValueError(f"image_dtype must be 'float32' or 'uint8', got {image_dtype!r}")
+    key = (path, tuple(img_res), base, image_dtype)
     if cache is not None and key in cache:
         arr, scale, left, top = cache.pop(key)
         cache[key] = (arr, scale, left, top)            # most recently used last
@@ -83,7 +87,7 @@ def load_image_rescaled_cropped(path: str, intrinsics: np.ndarray, img_res=(512,
     img = img.crop((left, top, left + final_w, top + final_h))
     intrinsics[0, -1] -= left
     intrinsics[1, -1] -= top
-    arr = np.array(img, dtype=np.float32) / 255.0
+    arr = np.array(img, dtype=np.float32) / 255.0 if image_dtype == "float32" else np.asarray(img, dtype=np.uint8)
     if arr.ndim == 2:
         arr = np.dstack((arr, arr, arr))
     if cache is not None and cache_size > 0:
@@ -98,8 +102,13 @@ class EvalDataset:
 
     def __init__(self, datapath, listfile, mode="test", nviews=5, ndepths=192, interval_scale=1.06,
                  pairfile="pair.txt", cam_subfolder="Cameras", img_subfolder="Rectified/{}/rect_{:0>3}_3_r5000.png",
-                 img_res=(512, 640), dataset_name="dtu", cache_images: int = 0):
+                 img_res=(512, 640), dataset_name="dtu", cache_images: int = 0, image_dtype: str = "float32"):
         assert mode == "test"
+        # "uint8": items carry the decoded 8-bit pixels ([N,3,H,W] uint8) instead of the reference's floats; the
+        # drop-in MVSNet.forward accepts them (same bits after its on-device division by 255)
+        if image_dtype not in ("float32", "uint8"):
+            raise ValueError(f"image_dtype must be 'float32' or 'uint8', got {image_dtype!r}")
+        self.image_dtype = image_dtype
         # decoded-image LRU (0 = off, the reference's behaviour: every sample decodes its views again)
         self.cache_images = int(cache_images)
         self._img_cache = {} if self.cache_images > 0 else None
@@ -131,11 +140,11 @@ class EvalDataset:
         return scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}", views
 
     def decode_view(self, img_path):
-        """The expensive part: decode + rescale + crop one image.  -> (float32 [3,H,W] contiguous in [0,1],
+        """The expensive part: decode + rescale + crop one image.  -> (float32 (or uint8) [3,H,W] contiguous in [0,1],
         (scale, left, top)): what the intrinsics of any sample using this view are adjusted by."""
         probe = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
         arr, probe = load_image_rescaled_cropped(img_path, probe, img_res=self.img_res, cache=self._img_cache,
-                                                 cache_size=self.cache_images)
+                                                 cache_size=self.cache_images, image_dtype=self.image_dtype)
         return np.ascontiguousarray(arr.transpose(2, 0, 1)), (float(probe[0, 0]), float(-probe[0, 2]), float(-probe[1, 2]))
 
     def assemble(self, idx, adjust):
@@ -174,7 +183,7 @@ class EvalDataset:
             cam_path = os.path.join(self.datapath, self.cam_subfolder, "{:0>8}_cam.txt".format(vid))
             intr, extr, dmin, dint = parse_cam_file(cam_path, self.interval_scale)
             img, intr = load_image_rescaled_cropped(img_path, intr, img_res=self.img_res, cache=self._img_cache,
-                                                    cache_size=self.cache_images)
+                                                    cache_size=self.cache_images, image_dtype=self.image_dtype)
             imgs.append(img)
             intr[:2, :] /= 4.0  # feature scale (the network downsamples by 4)
             intr_list.append(intr)

@@ -169,7 +169,10 @@ def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: i
             t0 = _now()
             per_view = isinstance(s["imgs"], (list, tuple))     # ViewDecoderPool: one shared-memory array per view
             pinned = False
-            src = [None if per_view else torch.as_tensor(np.asarray(s["imgs"]), dtype=torch.float32)[None]] + \
+            # uint8 pixels (EvalDataset(image_dtype="uint8")) travel as they are: the model divides by 255 on the device
+            u8 = (np.asarray(s["imgs"][0]) if per_view else np.asarray(s["imgs"])).dtype == np.uint8
+            idt = torch.uint8 if u8 else torch.float32
+            src = [None if per_view else torch.as_tensor(np.asarray(s["imgs"]), dtype=idt)[None]] + \
                   [torch.as_tensor(np.asarray(s[k]), dtype=torch.float32)[None] for k in ("proj_matrices", "depth_values")]
             _tick("loader.prep", t0)
             t0 = _now()
@@ -179,7 +182,7 @@ def _loader(dataset, indices, device, copy_stream, q: "queue.Queue", decoders: i
                 if per_view:   # N copies straight from the cache slots into the [1,N,3,H,W] device tensor
                     pinned = _pin_pool_memory(decoder_pool)
                     views = [torch.from_numpy(v) for v in s["imgs"]]
-                    imgs_dev = torch.empty((1, len(views)) + tuple(views[0].shape), dtype=torch.float32, device=device)
+                    imgs_dev = torch.empty((1, len(views)) + tuple(views[0].shape), dtype=idt, device=device)
                     small = [t.to(device) for t in src[1:]]   # pageable (synchronous) copies first: behind the
                     for i, v in enumerate(views):             # asynchronous ones they would wait for them
                         imgs_dev[0, i].copy_(v, non_blocking=pinned)
@@ -274,7 +277,10 @@ def save_depth_sharded(model, dataset, outdir: str, rank: int = 0, world: int = 
                     done.record(compute)
                     K = np.asarray(s["intrinsics"][0]) if "intrinsics" in s else None
                     E = np.asarray(s["extrinsics"][0]) if "extrinsics" in s else None
-                    img = np.asarray(s["imgs"][0], np.float32) if (save_images and s.get("imgs") is not None) else None
+                    img = None
+                    if save_images and s.get("imgs") is not None:
+                        img = np.asarray(s["imgs"][0])
+                        img = img.astype(np.float32) / np.float32(255.0) if img.dtype == np.uint8 else np.asarray(img, np.float32)
                     _tick("main.d2h_submit", t0)
                     t0 = _now()
                     cq.put((done, out, (outdir, s["filename"], K, E, img)))   # bounded: back-pressure

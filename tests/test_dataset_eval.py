@@ -58,6 +58,35 @@ def test_image_cache_gives_identical_samples(tmp_path):
     assert 0 < len(cached._img_cache) <= 3
 
 
+def test_uint8_items_are_the_reference_items_before_the_division(tmp_path):
+    """EvalDataset(image_dtype="uint8"): `imgs` are the decoded 8-bit pixels; the reference's conversion
+    (np.array(img, float32) / 255., datasets/data_io.py:143) applied to them afterwards gives the float item BIT FOR BIT
+    -- which is what the drop-in MVSNet does on the device.  Everything else of the item is unchanged, and the
+    shared-memory decoder ring ships the uint8 block as it is (a quarter of the bytes)."""
+    import os
+    from synthetic_dataset import write_synthetic_dataset
+    from scene_3dreconstruction_mvsnet_amd.dataset_eval import EvalDataset
+    from scene_3dreconstruction_mvsnet_amd.decoder_pool import DecoderPool
+    listfile = write_synthetic_dataset(str(tmp_path))
+    kw = dict(mode="test", nviews=3, ndepths=16, interval_scale=1.06, img_res=(96, 128), dataset_name="dtu")
+    f32 = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, **kw)
+    u8 = EvalDataset(os.path.join(str(tmp_path), "data"), listfile, image_dtype="uint8", cache_images=2, **kw)
+    for i in range(len(f32)):
+        a, b = f32[i], u8[i]
+        assert b["imgs"].dtype == np.uint8 and b["imgs"].shape == a["imgs"].shape
+        np.testing.assert_array_equal(b["imgs"].astype(np.float32) / np.float32(255.0), a["imgs"])
+        np.testing.assert_array_equal(a["proj_matrices"], b["proj_matrices"])
+        np.testing.assert_array_equal(a["depth_values"], b["depth_values"])
+        assert a["filename"] == b["filename"]
+    with DecoderPool(u8, procs=2, chunk=2, slots=4) as pool:
+        for i, s in zip(range(len(u8)), pool.imap(list(range(len(u8))))):
+            assert np.array(s["imgs"]).dtype == np.uint8 and np.array(s["imgs"]).nbytes * 4 == f32[i]["imgs"].nbytes
+            np.testing.assert_array_equal(np.array(s["imgs"]), u8[i]["imgs"])
+            pool.release(s)
+    with pytest.raises(ValueError):
+        EvalDataset(os.path.join(str(tmp_path), "data"), listfile, image_dtype="float16", **kw)
+
+
 def test_decoder_pool_delivers_the_dataset_in_order(tmp_path):
     """Worker processes + shared-memory ring: every sample equals dataset[i], in order, also when
     the consumer never releases explicitly and when there are more samples than slots."""

@@ -16,4 +16,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
 n=$(echo $pass | cut -d' ' -f1)
 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/traffic/$n -- python3 $GRAFT_REPO_ROOT/tools/prof_stage.py all 3 > /dev/null 2>&1
 done
-echo SESSION_DONE
+echo SESSION_DONE1
+# N > 1 plumbing on the one-GPU box: 4 ranks on cuda:0 over gloo (the box allows at most 6 processes on its GPU; the
+# launcher's agent process opens it too, so 6 ranks trip the guard -- measured in round 4)
+cd $GRAFT_REPO_ROOT
+MVS_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 4 --steps 4 --no-cpu-baseline --no-e2e > gpurun_out/rehearsal4.json 2> gpurun_out/rehearsal4.err || echo "rehearsal rc=$?"
+echo SESSION_DONE2
