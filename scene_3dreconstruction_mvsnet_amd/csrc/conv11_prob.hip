@@ -228,8 +228,12 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
             }
         }
     };
-    auto emit = [&](int oz, const f32x2v& sv) {
-        if (pvalid) cost[(size_t)oz * HWo + pout] = sv.x + sv.y;
+    // logits leave by raw buffer stores: a position that is not this block's to write gets an offset beyond the
+    // descriptor (dropped by the hardware) -- no branch around a VMEM instruction (see conv11_prob16_kernel)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(cost, (short)0, (int)((size_t)Do * HWo * 4), 0x00020000);
+    auto emit = [&](int oz, const f32x2v& sv, bool live) {
+        const unsigned off = (pvalid && live) ? (unsigned)(((size_t)oz * HWo + pout) * 4) : 0xFFFFFFFCu;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv.x + sv.y), crs, (int)off, 0, 0);
     };
 
     const float pb = pbias[0];
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
         __builtin_amdgcn_wave_barrier();
         store_a();                                   // after chunk 0's reads in this wave's LDS order
         __builtin_amdgcn_wave_barrier();
-        if (i < i_last) load_a(i + 1, 0);
+        load_a(min(i + 1, i_last), 0);               // unconditional (after the last step: a re-read nobody uses)
         mfma_chunk(1, de, dodd);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -278,26 +282,21 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
                 *reinterpret_cast<f32x4*>(ct + sl[2 * pz + j]) =
                     ((sok >> (2 * pz + j)) & 1u) ? t[j] + sk[2 * pz + j] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (i < i_last) load_skip(i + 1, true, i + 1 < zb);
+        load_skip(min(i + 1, i_last), true, i + 1 < zb);   // unconditional
         __syncthreads();
         // ---- the whole tile: stencil ----
-        if (de) {            // even plane 2i: completes logit 2i - 1
-            stencil(0, A, B, C);
-            if (i > za) emit(2 * i - 1, A);
-        }
+        if (de) stencil(0, A, B, C);           // even plane 2i: completes logit 2i - 1
+        emit(max(2 * i - 1, 0), A, de && i > za);
         A = fresh;
-        if (dodd) {          // odd plane 2i + 1: completes logit 2i
-            stencil(1, B, C, A);
-            if (de) emit(2 * i, B);
-        }
+        if (dodd) stencil(1, B, C, A);         // odd plane 2i + 1: completes logit 2i
+        emit(2 * i, B, dodd && de);
         const f32x2v t = A;  // (A, B, C) <- logits (2i+1, 2i+2, 2i+3)
         A = C;
         B = t;
         C = fresh;
         __syncthreads();
     }
-    if (zb == Di) emit(Do - 1, A);   // the volume's last plane has no successor to complete it
-    (void)Do;
+    emit(Do - 1, A, zb == Di);   // the volume's last plane has no successor to complete it
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -470,8 +469,14 @@ __global__ __launch_bounds__(512, 4) void conv11_prob16_kernel(
             }
         }
     };
-    auto emit = [&](int oz, const f32x2v& sv) {
-        if (pvalid) cost[(size_t)oz * HWo + pout] = sv.x + sv.y;
+    // logits leave by raw buffer stores: a position that is not this block's to write gets an offset beyond the
+    // descriptor (dropped by the hardware) -- no branch around a VMEM instruction, so hipcc keeps COUNTED vmcnt waits
+    // for the loads requested a step ahead (round 4: with conditional loads / stores the ISA had vmcnt(1) / vmcnt(0)
+    // right behind the prefetch of the NEXT step)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(cost, (short)0, (int)((size_t)Do * HWo * 4), 0x00020000);
+    auto emit = [&](int oz, const f32x2v& sv, bool live) {
+        const unsigned off = (pvalid && live) ? (unsigned)(((size_t)oz * HWo + pout) * 4) : 0xFFFFFFFCu;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv.x + sv.y), crs, (int)off, 0, 0);
     };
 
     const float pb = pbias[0];
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob16_kernel(
         // operations in order; wave_barrier() keeps the compiler from reordering across these points)
         store_a();                                   // both chunks of planes i, i + 1 (requested a step ago)
         __builtin_amdgcn_wave_barrier();
-        if (i < i_last) load_a(i + 1);
+        load_a(min(i + 1, i_last));                  // unconditional (after the last step: a re-read nobody uses)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mfma_all();
@@ -514,26 +519,21 @@ __global__ __launch_bounds__(512, 4) void conv11_prob16_kernel(
             *reinterpret_cast<f32x4*>(d) = sok ? t0 + (f32x4){sv[0], sv[1], sv[2], sv[3]} : z4;
             *reinterpret_cast<f32x4*>(d + HS) = sok ? t1 + (f32x4){sv[4], sv[5], sv[6], sv[7]} : z4;
         }
-        if (i < i_last) load_skip(i + 1, true, i + 1 < zb);
+        load_skip(min(i + 1, i_last), true, i + 1 < zb);   // unconditional
         __syncthreads();
         // ---- the whole tile: stencil ----
-        if (de) {            // even plane 2i: completes logit 2i - 1
-            stencil(0, A, B, C);
-            if (i > za) emit(2 * i - 1, A);
-        }
+        if (de) stencil(0, A, B, C);           // even plane 2i: completes logit 2i - 1
+        emit(max(2 * i - 1, 0), A, de && i > za);
         A = fresh;
-        if (dodd) {          // odd plane 2i + 1: completes logit 2i
-            stencil(1, B, C, A);
-            if (de) emit(2 * i, B);
-        }
+        if (dodd) stencil(1, B, C, A);         // odd plane 2i + 1: completes logit 2i
+        emit(2 * i, B, dodd && de);
         const f32x2v t = A;  // (A, B, C) <- logits (2i+1, 2i+2, 2i+3)
         A = C;
         B = t;
         C = fresh;
         __syncthreads();
     }
-    if (zb == Di) emit(Do - 1, A);   // the volume's last plane has no successor to complete it
-    (void)Do;
+    emit(Do - 1, A, zb == Di);   // the volume's last plane has no successor to complete it
 }
 
 bool conv11_prob_enabled(int dtype) {   // MVS_FUSE_PROB=0: conv11 and prob as two launches (A/B runs)
