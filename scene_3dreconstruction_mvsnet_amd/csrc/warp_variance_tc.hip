@@ -212,8 +212,18 @@ __device__ __forceinline__ int pair_pick(int v) {
 template <int Q>
 __device__ __forceinline__ float pair_pick(float v) { return __int_as_float(pair_pick<Q>(__float_as_int(v))); }
 
-template <int DT, int FDT, int NV, int CPT, int NTS, int PAIR>
-__global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
+// PK = 1 (16-bit features, CPT = 4 only; experiment of round 4): the cached taps stay PACKED (8 instead of
+// 16 VGPRs per view) and are widened inside the blend at every step -- bit-identical results (widening is exact), fewer
+// registers (more resident waves), more vector instructions per step.  Measured: section 10 of DESIGN.md.
+#if MVS_ABLATE == 61
+#define MVS_WARP_LB __launch_bounds__(256, 4)
+#elif MVS_ABLATE == 62
+#define MVS_WARP_LB __launch_bounds__(256, 5)
+#else
+#define MVS_WARP_LB __launch_bounds__(256)
+#endif
+template <int DT, int FDT, int NV, int CPT, int NTS, int PAIR, int PK = 0>
+__global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
                                                                 const float* __restrict__ rt,
                                                                 const float* __restrict__ dv,
                                                                 void* __restrict__ var, int N, int D, int h,
@@ -267,7 +277,9 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
     const float qz = fmaf(r[6], fx, fmaf(r[7], fy, r[8]));
     const float tx = r[9], ty = r[10], tz = r[11];
 
-    f32x4 tap[NV][4][NH];  // cached taps: [view][00,01,10,11][16-byte piece]
+    static_assert(!PK || (CPT == 4 && FDT != MVS_F32), "packed tap cache: 16-bit features, 4 channels per thread");
+    f32x4 tap[PK ? 1 : NV][4][NH];  // cached taps: [view][00,01,10,11][16-byte piece]
+    u32x2 tapk[PK ? NV : 1][4];     // PK: the same taps as stored (4 x 16 bit)
     int key[NV];           // cell key of the cached taps
 #pragma unroll
     for (int v = 0; v < NV; ++v) key[v] = -1;
@@ -286,10 +298,17 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
                 const unsigned o00 = (unsigned)k >> 2, dx = (unsigned)k & 1u, dyw = (k & 2) ? (unsigned)w : 0u;
                 const unsigned b00 = plane_b + o00 * (8u * FES);
                 const unsigned soff = (unsigned)(v + 1) * view_b;
-                gather_tap_buf<FDT, CPT>(tap[v][0], frs, b00, soff);
-                gather_tap_buf<FDT, CPT>(tap[v][1], frs, b00 + dx * (8u * FES), soff);
-                gather_tap_buf<FDT, CPT>(tap[v][2], frs, b00 + dyw * (8u * FES), soff);
-                gather_tap_buf<FDT, CPT>(tap[v][3], frs, b00 + (dyw + dx) * (8u * FES), soff);
+                if constexpr (PK) {
+                    tapk[v][0] = __builtin_amdgcn_raw_buffer_load_b64(frs, (int)b00, (int)soff, 0);
+                    tapk[v][1] = __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(b00 + dx * (8u * FES)), (int)soff, 0);
+                    tapk[v][2] = __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(b00 + dyw * (8u * FES)), (int)soff, 0);
+                    tapk[v][3] = __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(b00 + (dyw + dx) * (8u * FES)), (int)soff, 0);
+                } else {
+                    gather_tap_buf<FDT, CPT>(tap[v][0], frs, b00, soff);
+                    gather_tap_buf<FDT, CPT>(tap[v][1], frs, b00 + dx * (8u * FES), soff);
+                    gather_tap_buf<FDT, CPT>(tap[v][2], frs, b00 + dyw * (8u * FES), soff);
+                    gather_tap_buf<FDT, CPT>(tap[v][3], frs, b00 + (dyw + dx) * (8u * FES), soff);
+                }
                 key[v] = k;
             }
         }
@@ -311,10 +330,24 @@ __global__ __launch_bounds__(256) void warp_variance_tc2_kernel(const void* __re
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int hh = j >> 1, q = (j & 1) * 2;
-                const f32x2 a = {tap[v][0][hh][q], tap[v][0][hh][q + 1]};
-                const f32x2 bb = {tap[v][1][hh][q], tap[v][1][hh][q + 1]};
-                const f32x2 c = {tap[v][2][hh][q], tap[v][2][hh][q + 1]};
-                const f32x2 e = {tap[v][3][hh][q], tap[v][3][hh][q + 1]};
+                f32x2 a, bb, c, e;
+                if constexpr (PK) {
+                    auto widen = [](unsigned d) -> f32x2 {   // two 16-bit values of one dword -> fp32 (exact)
+                        if constexpr (FDT == MVS_F16) {
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            const h2 h = __builtin_bit_cast(h2, d);
+                            return (f32x2){(float)h[0], (float)h[1]};
+                        } else {
+                            return (f32x2){__uint_as_float(d << 16), __uint_as_float(d & 0xFFFF0000u)};
+                        }
+                    };
+                    a = widen(tapk[v][0][j]); bb = widen(tapk[v][1][j]); c = widen(tapk[v][2][j]); e = widen(tapk[v][3][j]);
+                } else {
+                    a = (f32x2){tap[v][0][hh][q], tap[v][0][hh][q + 1]};
+                    bb = (f32x2){tap[v][1][hh][q], tap[v][1][hh][q + 1]};
+                    c = (f32x2){tap[v][2][hh][q], tap[v][2][hh][q + 1]};
+                    e = (f32x2){tap[v][3][hh][q], tap[v][3][hh][q + 1]};
+                }
                 // a*w00 + (b*w01 + (c*w10 + e*w11)) -- the plain kernel's nesting, per component
                 const f32x2 wv = __builtin_elementwise_fma(a, W00, __builtin_elementwise_fma(bb, W01,
                                  __builtin_elementwise_fma(c, W10, e * W11)));
@@ -419,7 +452,15 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
     const unsigned npb = (h * w + pix - 1) / pix, nsl = (D + slab - 1) / slab;
     const dim3 grid = df ? dim3(nsl, npb) : dim3(npb, nsl);
     // PAIR = 1: one projection pass per two depth steps (quad q of a pixel evaluates depth d + q)
-#define MVS_TC2(NV) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df);
+    // MVS_WARP_PACKED=1 (16-bit features only): the packed tap cache
+    static const bool packed = [] {
+        const char* e = getenv("MVS_WARP_PACKED");
+        return e && e[0] == '1';
+    }();
+    constexpr int CANPK = FDT != MVS_F32 ? 1 : 0;
+#define MVS_TC2(NV)                                                                                                        \
+    if (CANPK && packed) warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0, 1, CANPK><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df); \
+    else warp_variance_tc2_kernel<DT, FDT, NV, CPT, 0, 1><<<grid, 256, 0, s>>>(feats_p, rt, dv, var, N, D, h, w, slab, df);
     switch (N - 1) {
         case 1: MVS_TC2(1) break;
         case 2: MVS_TC2(2) break;

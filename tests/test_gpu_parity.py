@@ -335,6 +335,33 @@ def test_optin_kernel_variants(env):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_packed_tap_cache_is_bit_identical():
+    """MVS_WARP_PACKED=1 (round-4 experiment): the 16-bit taps stay packed in the register cache and are
+    widened inside the blend -- the variance volume must be the default kernel's, bit for bit, for fp16 and bf16."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
+        "from scene_3dreconstruction_mvsnet_amd import _lib, synthetic\n"
+        "for st in ('f16', 'bf16'):\n"
+        "    dt = _lib.dtype_code(st); N, h, w, D = 5, 40, 56, 48\n"
+        "    f = torch.from_numpy(synthetic.random_features(N, 32, h, w, seed=3)).cuda()\n"
+        "    p = torch.from_numpy(synthetic.cameras(N, h, w, yaw_deg=1.0)).cuda()\n"
+        "    dv = torch.from_numpy(synthetic.depth_values(D)).cuda()\n"
+        "    ws = _lib.alloc_workspace(N, 32, D, h, w, 'cuda:0', dt)\n"
+        "    v = _lib.warp_variance(f, _lib.relative_proj(p), dv, ws, dtype=dt)\n"
+        "    print(st, hashlib.sha1(v.cpu().view(torch.int16).numpy().tobytes()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = []
+    for pk in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVS_WARP_PACKED=pk), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == 2, outs
+
+
 @pytest.mark.parametrize("storage", ["f16", "bf16"])
 def test_16bit_storage_fp32_feature_copy_variant(storage):
     """MVS_FEAT16=0: the 16-bit modes gather from the fp32 feature copy (features not narrowed); against the oracle
