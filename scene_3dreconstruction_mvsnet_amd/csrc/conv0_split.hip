@@ -306,7 +306,10 @@ constexpr int c43p_MAXT = 512;   // tiles per block the origin table holds (the 
 typedef float sf32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 sbf16x2 __attribute__((ext_vector_type(2)));
 
-// packed = (bf16(a.x), bf16(a.y)) RNE; returns a - widen(packed) (exact)
+// packed = (bf16(a.x), bf16(a.y)) RNE; returns a - widen(packed) (exact).  (Tried: the residual as one
+// v_dot2c_f32_bf16 per value, D += h . (-1, 0) -- 14 instead of 18 instructions per 4 values.  The build was not faster
+// (0.283 vs 0.276-0.283 ms) and its results were WRONG (heavy-tailed test 7.5e4 x its bound): the packed-bf16 inline
+// constant hipcc emits for (-1, 0) is not what the instruction reads.  Dropped.)
 __device__ __forceinline__ sf32x2 split_stage(const sf32x2 a, unsigned& packed) {
     const sbf16x2 h = __builtin_convertvector(a, sbf16x2);
     packed = __builtin_bit_cast(unsigned, h);

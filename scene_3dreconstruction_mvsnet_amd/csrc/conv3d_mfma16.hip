@@ -1240,13 +1240,14 @@ bool split_layer_covers(int layer) {
         const char* e = getenv("MVS_SPLIT_LAYERS");
         return e && e[0] == '2';
     }();
-    return layer >= 2 && layer <= (all ? 6 : 4);
+    return layer >= (all ? 1 : 2) && layer <= (all ? 6 : 4);
 }
 int launch_layer_split(int layer, const void* x, const void* skip, void* y, const void* panel, const float* bias,
                        int Di, int Hi, int Wi, hipStream_t s) {
     const unsigned short* bp = static_cast<const unsigned short*>(panel);
     (void)skip;
     switch (layer) {
+        case 1: return run_convgs<8, 16, 2, 2, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 2: return run_convgs<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 3: return run_convgs<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 4: return run_convgs<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
