@@ -501,7 +501,11 @@ __global__ __launch_bounds__(512) void conv0_w43p_kernel(
                 if constexpr (LOAD)
                     stg[SET ^ 1][i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff[i][t], 0, 0));
                 su32x2 p1, p2, p3;
+#if MVS_ABLATE == 74   // diagnostic: no split arithmetic
+                p1 = p2 = p3 = (su32x2){__float_as_uint(u[t].x), __float_as_uint(u[t].z)};
+#else
                 split3x(u[t], p1, p2, p3);
+#endif
                 su32x2* dst = t8 + t * (PLANE_E / 4) + loff[i];
                 dst[0] = p1;
                 dst[PIECE_E / 4] = p2;
@@ -609,8 +613,13 @@ __global__ __launch_bounds__(512) void conv0_w43p_kernel(
             if (c == 1) output(kk > 0 ? kk - 1 : 0, kk > 0);   // (c == 1: the step where the producers are slowest)
             constexpr unsigned bnext = (unsigned)(((c + 1) & 3) * NT_PLANES * 9) * 1024u;   // next step's chunk (wraps around)
             MVS_PTICK(kk, 4 * c + 1)
+#if MVS_ABLATE == 71   // diagnostic: no MFMA phase
+            if (D < 0)
+#endif
+            {
             if (cw & 1) c43p_step_mfmas<1>(buf + PB * TILE_E, aoff, B[PB], B[PB ^ 1], brs, bvoff, bnext, acc);
             else c43p_step_mfmas<0>(buf + PB * TILE_E, aoff, B[PB], B[PB ^ 1], brs, bvoff, bnext, acc);
+            }
             MVS_PTICK(kk, 4 * c + 2)
             if (c == 3) exchange();   // the producers read it during the next step (after the barrier)
             MVS_PTICK(kk, 4 * c + 3)
