@@ -689,6 +689,7 @@ int launch_conv0_wino43_split(const void* x, void* y, const void* bp, const floa
         const char* e = getenv("MVS_CONV0_SPLIT");
         return e && e[0] == '2';
     }();
+
     if (!form1) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
