@@ -119,6 +119,8 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
     else:
         for n in ("prob", "conv11_prob", "softargmin"):
             ex[n]["bytes"] = costs[n]["bytes"] + V0 * 2
+        if env.get("MVS_FEAT16") != "1":     # the warp gathers from the fp32 feature copy
+            ex["warp_variance"]["bytes"] = costs["warp_variance"]["bytes"] + N * 32 * h * w * 2
     return ex
 
 

@@ -275,10 +275,10 @@ def costreg_state(full_state: dict) -> dict:
     return out
 
 
-def depth_infer(features, proj_matrices, depth_values, sd, storage="f32", arith16=True, feat16=True):
+def depth_infer(features, proj_matrices, depth_values, sd, storage="f32", arith16=True, feat16=False):
     """The whole hot path after FeatureNet for one batch item (models/mvsnet.py:145-218).
-    With 16-bit storage the defaults match the HIP path's defaults: 16-bit MFMA operands and a
-    16-bit copy of the features for the warp gather."""
+    With 16-bit storage the defaults match the HIP path's defaults: 16-bit MFMA operands, and (since round 4) the fp32
+    features for the warp gather; feat16=True = a 16-bit copy of the features (the HIP path's MVS_FEAT16=1)."""
     feats = round_storage(_f32(features), storage) if feat16 else features
     var = round_storage(variance_volume(feats, proj_matrices, depth_values), storage)
     cost = costreg_forward(var, sd, storage, arith16=arith16)

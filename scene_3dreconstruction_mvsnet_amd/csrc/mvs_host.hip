@@ -43,11 +43,14 @@ static int check_dims(int N, int C, int D, int h, int w, int dtype) {
     return MVS_OK;
 }
 
-// 16-bit modes: the feature copy is narrowed too (half the gather bytes) unless MVS_FEAT16=0
+// 16-bit modes: the warp gathers from the fp32 feature copy (round 4: the kernel is bound by vector-instruction issue,
+// and widening 16-bit taps on every re-gather costs more than the halved gather bytes save -- cfg3 bf16 1.379 -> 1.347
+// ms, cfg5 fp16 0.1226 -> 0.1131; the features then are not rounded at all).  MVS_FEAT16=1: the narrowed copy (the
+// default of rounds 2-3)
 bool feat16_gather() {
     static const bool on = [] {
         const char* e = getenv("MVS_FEAT16");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     return on;
 }

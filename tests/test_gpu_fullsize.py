@@ -220,7 +220,7 @@ def test_16bit_configs_per_stage_and_against_the_fp32_oracle(cfg_name, storage):
         _FP32_ORACLE[cfg_name] = (v, orc.softargmin_conf(orc.costreg_forward(v, sd), dv)[0])
     var32, d32 = _FP32_ORACLE[cfg_name]
     var_m = var32 if storage == "f32" else orc.round_storage(
-        orc.variance_volume(orc.round_storage(feats, storage), proj, dv), storage)
+        orc.variance_volume(feats, proj, dv), storage)
     got = _lib.from_c8(hip_variance_c8(feats, proj, dv, code).float()).cpu().numpy()
     eps = {"f32": 0.0, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[storage]
     np.testing.assert_allclose(got, var_m, rtol=eps, atol=5e-4)

@@ -363,9 +363,9 @@ def test_packed_tap_cache_is_bit_identical():
 
 
 @pytest.mark.parametrize("storage", ["f16", "bf16"])
-def test_16bit_storage_fp32_feature_copy_variant(storage):
-    """MVS_FEAT16=0: the 16-bit modes gather from the fp32 feature copy (features not narrowed); against the oracle
-    with the usual rounding points -- the un-rounded features move the depth far less than the bound."""
+def test_16bit_storage_16bit_feature_copy_variant(storage):
+    """MVS_FEAT16=1: the 16-bit modes gather from a feature copy narrowed to the storage type (the default of rounds
+    2-3; since round 4 the gather reads the fp32 copy); against the oracle with the same rounding point."""
     import os
     import subprocess
     import sys
@@ -381,10 +381,10 @@ def test_16bit_storage_fp32_feature_copy_variant(storage):
         "ws = _lib.alloc_workspace(N, C, d.shape[0], h, w, dev, dt)\n"
         "depth = torch.empty((h, w), device=dev); conf = torch.empty_like(depth)\n"
         "_lib.depth_infer(cu(f), cu(p), cu(d), _lib.pack_weights(sd).to(dev), ws, depth, conf, dtype=dt)\n"
-        "want, _ = orc.depth_infer(f, p, d, sd, storage=st)\n"
+        "want, _ = orc.depth_infer(f, p, d, sd, storage=st, feat16=True)\n"
         "r = rel_l1(depth.cpu().numpy(), want); print(r); sys.exit(0 if r < (2e-4 if st == 'f16' else 1e-3) else 1)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), storage)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVS_FEAT16="0"),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVS_FEAT16="1"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -542,8 +542,8 @@ def test_16bit_layers_match_matched_oracle(storage):
     ws = _lib.alloc_workspace(feats.shape[0], 32, dv.shape[0], feats.shape[2], feats.shape[3], DEV, code)
     var = _lib.warp_variance(cu(feats), _lib.relative_proj(cu(proj)), cu(dv), ws, dtype=code)
     assert var.dtype == tdt
-    # 16-bit modes gather from a 16-bit copy of the features (fp32 interpolation / variance)
-    want = orc.round_storage(orc.variance_volume(orc.round_storage(feats, storage), proj, dv), storage)
+    # 16-bit modes: fp32 features, fp32 interpolation / variance, the volume narrowed in the store
+    want = orc.round_storage(orc.variance_volume(feats, proj, dv), storage)
     eps = 2.0 ** (-10 if storage == "f16" else -7)
     got = _lib.from_c8(var.float()).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=eps, atol=5e-4)

@@ -520,6 +520,7 @@ def test_bench_roofline_fractions_never_exceed_one():
     assert e16["softargmin"]["bytes"] == c16["softargmin"]["bytes"] + 2 * V0
     assert e16["conv11_prob"]["bytes"] == c16["conv11_prob"]["bytes"] + 2 * V0
     assert e16["conv0"] == c16["conv0"]
+    assert e16["warp_variance"]["bytes"] == c16["warp_variance"]["bytes"] + 5 * 32 * 296 * 400 * 2   # fp32 feature gather
     rw = bench.roofline_entry("warp_variance", 1.3, c16["warp_variance"], e16["warp_variance"], bench.mfma_peak_tflops("bf16"))
     assert rw["bound"] == "hbm" and rw["frac"] < 0.25
 
