@@ -440,6 +440,9 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_CONV1Z": "1"}, ("24", "24", "40", "f32")),
     ({"MVS_CONV1Z": "1"}, ("16", "16", "32", "f32")),
     ({"MVS_CONV1Z": "0"}, ("16", "16", "32", "f32")),
+    # the split-operand z-marching conv1 (conv1zs, round 4; measured slower, so only MVS_SPLIT_LAYERS=2 selects it)
+    ({"MVS_CONV1Z": "1", "MVS_SPLIT_LAYERS": "2"}, ("24", "24", "40", "f32")),
+    ({"MVS_CONV1Z": "1", "MVS_SPLIT_LAYERS": "2"}, ("16", "16", "32", "f32")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a

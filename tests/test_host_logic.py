@@ -505,6 +505,7 @@ def test_bench_roofline_fractions_never_exceed_one():
     ex = bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_SPLIT": "0", "MVS_SPLIT_LAYERS": "0"})
     assert abs(ex["conv2"]["flops"] / costs["conv2"]["flops"] - 20 / 27) < 1e-12
     assert ex["conv1"] == costs["conv1"] and ex["conv0"]["bytes"] == costs["conv0"]["bytes"]
+    assert exs["conv1"] == costs["conv1"]      # conv1 stays on the fp32-MFMA z-marching kernel
     assert bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_WINO": "0"})["conv0"]["flops"] == costs["conv0"]["flops"]
     # round 3's driver line: conv0 0.3441 ms -> algorithmic 1.0043 of the fp32 MFMA peak, executed 0.502
     peak = bench.mfma_peak_tflops("f32")
