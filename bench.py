@@ -107,9 +107,9 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
                     ex["conv0"]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
                     ex["conv0"]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"
             if env.get("MVS_SPLIT_LAYERS") != "0":
-                # conv2 .. conv4 (.. conv6 with MVS_SPLIT_LAYERS=2): split operands on the bf16 matrix cores, six cross
-                # products per product, 27 taps padded to 28 (csrc/conv3d_mfma16.hip convgs)
-                for n in ("conv2", "conv3", "conv4") + (("conv1", "conv5", "conv6") if env.get("MVS_SPLIT_LAYERS") == "2" else ()):
+                # conv2 .. conv4: split operands on the bf16 matrix cores, six cross products per product, 27 taps padded
+                # to 28 (csrc/conv3d_mfma16.hip convgs)
+                for n in ("conv2", "conv3", "conv4"):
                     ex[n]["flops"] = costs[n]["flops"] * 6.0 * 28.0 / 27.0
                     ex[n]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
                     ex[n]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"

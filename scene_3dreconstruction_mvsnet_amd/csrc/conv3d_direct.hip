@@ -485,10 +485,8 @@ int launch_conv_layer(int layer, const void* x, const void* skip, void* y, const
         const char* e = getenv("MVS_SPLIT_LAYERS");
         return !(e && e[0] == '0');
     }();
-    if (split_layers && dtype == MVS_F32 && split_layer_covers(layer)) {
-        const int st = launch_layer_split(layer, x, skip, y, blob + L.s16_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
-        if (st != -1) return st;   // -1: no split kernel for this layer at this shape (conv1 below the z-marching size)
-    }
+    if (split_layers && dtype == MVS_F32 && split_layer_covers(layer))
+        return launch_layer_split(layer, x, skip, y, blob + L.s16_off[layer], blob + L.b_off[layer], Di, Hi, Wi, s);
     if (layer == 2 || layer == 4) {
         // stride-1 layers conv2 / conv4: Winograd F(2,3) along z (conv_winograd.hip) unless
         // MVS_CONV_WINO=0.  conv6 (64 -> 64 on 7,680 voxels) stays direct: with two-plane tiles it has

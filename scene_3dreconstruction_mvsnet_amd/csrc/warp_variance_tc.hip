@@ -440,18 +440,14 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
                   hipStream_t s) {
     constexpr int CPT = 4;                 // 8 lanes per pixel, 16 waves per CU (CPT = 8: 0.166 vs 0.157 ms at cfg2)
     // depths a thread marches through (cfg2, kernel + transpose: 8 / 12 / 16 / 24 / 32 / 48 / 64 = 0.183 / 0.172 / 0.168 /
-    // 0.161 / 0.160 / 0.160 / 0.159 ms).  MVS_WARP_SLAB=n overrides it (diagnostic sweeps: tools/gpu/warp_slab.sh)
-    static const int slab_env = [] {
-        const char* e = getenv("MVS_WARP_SLAB");
-        return e ? atoi(e) : 0;
-    }();
+    // 0.161 / 0.160 / 0.160 / 0.159 ms in round 3)
     // Round 4 sweep (bench per-kernel pass, cfg2 / cfg5 / cfg3): 12: 0.168 / 0.129 / 1.63; 20: 0.160 / 0.122 / 1.48; 24: 0.157
     // / 0.122 / 1.46; 28: 0.157 / 0.122 / 1.52; 40: 0.155 / 0.120 / 1.44; 52: 0.156 / 0.121 / 1.44; 88: 0.163 / 0.131 / 1.44
     // -- and a slab count that is a multiple of 8 is a trap in the depth-slab-fastest order (cfg3, D = 256: slab 16 /
     // 32 / 64 = 1.95 / 1.86 / 1.78 ms): the linear block id then sends slab s of EVERY pixel block to XCD s % 8, so every
     // XCD's L2 streams the whole feature set
-    int slab = slab_env > 0 ? slab_env : 40;
-    if (slab_env <= 0 && ((D + slab - 1) / slab) % 8 == 0) slab += 4;
+    int slab = 40;
+    if (((D + slab - 1) / slab) % 8 == 0) slab += 4;
     constexpr int pix = 256 / (32 / CPT);
     constexpr size_t fes = FDT == MVS_F32 ? 4 : 2;
     // all views' features against the 32 MB of aggregate L2 (MVS_WARP_DEPTH_FASTEST=1 forces the order)

@@ -317,7 +317,6 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_WINO": "0", "MVS_CONV_WINO": "0"},   # direct MFMA kernels (no Winograd transform anywhere)
     {"MVS_CONV0_SPLIT": "0"},    # conv0 on the fp32 MFMA (Winograd F(4,3)) instead of split bf16 operands
     {"MVS_SPLIT_LAYERS": "0"},   # conv2 .. conv4 on the fp32 MFMA (Winograd F(2,3) / generic kernels)
-    {"MVS_SPLIT_LAYERS": "2"},   # conv5 / conv6 on the split-operand tile kernel too
     {"MVS_CONV0_SPLIT": "2"},    # the split-operand conv0 in its first form (one tile per 4-wave block)
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
@@ -440,9 +439,6 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_CONV1Z": "1"}, ("24", "24", "40", "f32")),
     ({"MVS_CONV1Z": "1"}, ("16", "16", "32", "f32")),
     ({"MVS_CONV1Z": "0"}, ("16", "16", "32", "f32")),
-    # the split-operand z-marching conv1 (conv1zs, round 4; measured slower, so only MVS_SPLIT_LAYERS=2 selects it)
-    ({"MVS_CONV1Z": "1", "MVS_SPLIT_LAYERS": "2"}, ("24", "24", "40", "f32")),
-    ({"MVS_CONV1Z": "1", "MVS_SPLIT_LAYERS": "2"}, ("16", "16", "32", "f32")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a
