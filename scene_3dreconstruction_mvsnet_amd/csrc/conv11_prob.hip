@@ -86,7 +86,14 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_priv_kernel(
     __shared__ __attribute__((aligned(16))) float bpan[2 * 9 * 64 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    // blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD: speed only, never correctness) and
+    // every XCD has its own L2: XCD k works through the k-th eighth of the (z chunk, row, column) sequence, so that
+    // tiles sharing a halo column / row (and the skip planes both read) run on the same L2 at about the same time
+    int b;
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;   // XCD k runs q (+1 if k < rem) blocks
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
@@ -350,7 +357,14 @@ __global__ __launch_bounds__(512, 4) void conv11_prob16_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short win[8 * 2 * WIN];   // [wave][chunk][plane 2][row 3][RPI]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    // blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD: speed only, never correctness) and
+    // every XCD has its own L2: XCD k works through the k-th eighth of the (z chunk, row, column) sequence, so that
+    // tiles sharing a halo column / row (and the skip planes both read) run on the same L2 at about the same time
+    int b;
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;   // XCD k runs q (+1 if k < rem) blocks
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
