@@ -89,6 +89,26 @@ __device__ __forceinline__ int quad_bcast(int v, int lane) {
 // non-temporal stores (slower); depth slabs of 48 / 96 (the 5,120 blocks of slab 24 are exactly five
 // rounds of the 1,024 resident blocks).
 // ---------------------------------------------------------------------------------------------
+
+// v_pk_fma_f32 / v_pk_mul_f32 with ONE half of the weight pair `w` broadcast to both lanes (op_sel): two bilinear weights
+// share an aligned register pair.  Written as asm because hipcc turns every such splat back into a scalar splat, which
+// occupies an aligned PAIR per weight with the odd register wasted (8 instead of 4 VGPRs for the four weights of a view).
+__device__ __forceinline__ f32x2 pk_fma_wlo(f32x2 a, f32x2 w, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_whi(f32x2 a, f32x2 w, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_whi(f32x2 a, f32x2 w) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(w));
+    return d;
+}
+
 struct SampK {
     int key;                    // (o00 << 2) | (dy << 1) | dx : the view's clamped 2x2 cell
     float w00, w01, w10, w11;   // bilinear weights (0 outside the image, NaN for non-finite coordinates)
@@ -326,7 +346,7 @@ __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ fe
         for (int v = 0; v < NV; ++v) {
             const float w00 = quad_bcast(mw00, v), w01 = quad_bcast(mw01, v);
             const float w10 = quad_bcast(mw10, v), w11 = quad_bcast(mw11, v);
-            const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+            const f32x2 P0 = {w00, w01}, P1 = {w10, w11};   // two weights per register pair (pk_*_wlo / _whi)
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int hh = j >> 1, q = (j & 1) * 2;
@@ -349,8 +369,7 @@ __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ fe
                     e = (f32x2){tap[v][3][hh][q], tap[v][3][hh][q + 1]};
                 }
                 // a*w00 + (b*w01 + (c*w10 + e*w11)) -- the plain kernel's nesting, per component
-                const f32x2 wv = __builtin_elementwise_fma(a, W00, __builtin_elementwise_fma(bb, W01,
-                                 __builtin_elementwise_fma(c, W10, e * W11)));
+                const f32x2 wv = pk_fma_wlo(a, P0, pk_fma_whi(bb, P0, pk_fma_wlo(c, P1, pk_mul_whi(e, P1))));
                 S[j] = S[j] + wv;
                 Q[j] = __builtin_elementwise_fma(wv, wv, Q[j]);
             }
