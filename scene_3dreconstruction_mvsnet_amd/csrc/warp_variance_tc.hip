@@ -276,11 +276,12 @@ __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ fe
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(var, (short)0, (int)vbytes, 0x00020000);
     const unsigned plane_b = ((unsigned)pl * (unsigned)N * (unsigned)hw * 8u + (unsigned)cin) * FES;   // this thread's channels of view 0, texel 0
     const unsigned view_b = (unsigned)hw * 8u * FES;                                  // bytes per view (scalar)
-    // the depth plane advances in the vector offset (see store_voxel_buf); out-of-range lanes of the last
-    // block stay beyond the descriptor's range: offset 0xFFFFFFE0 (+16 must not wrap), step 0
-    const unsigned dstep_v = live ? (unsigned)hw * 8u * VES : 0u;
+    // the depth plane advances in the vector offset (see store_voxel_buf) by a UNIFORM step (an SGPR: one VGPR less --
+    // the 128th); out-of-range lanes of the last block start so far beyond the descriptor's range that `slab` steps
+    // neither reach 2^32 nor come back into it: 0xFFFFFFE0 - slab * step >= vbytes (warp_tc_fits checks it)
+    const unsigned dstep_v = (unsigned)hw * 8u * VES;
     unsigned out_v = live ? ((((unsigned)pl * (unsigned)D + (unsigned)d0) * (unsigned)hw + (unsigned)p) * 8u + (unsigned)cin) * VES
-                          : 0xFFFFFFE0u;
+                          : 0xFFFFFFE0u - (unsigned)slab * dstep_v;
 
     f32x4 rf[NH];
     gather_tap_buf<FDT, CPT>(rf, frs, plane_b + (unsigned)p * 8u * FES, 0u);
@@ -504,8 +505,9 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
 // (16 VGPRs of cached taps per source view).  Other problems run the plain kernel (warp_variance.hip).
 bool warp_tc_fits(int N, int D, int h, int w, int fes, int ves) {
     const size_t hw = (size_t)h * w;
+    // (+ 48 depth planes of one channel plane: the parking range of the last block's out-of-image lanes, slab <= 44)
     return N >= 2 && N <= 5 && 4 * (size_t)N * hw * 8 * fes < ((size_t)1 << 31) &&
-           4 * (size_t)D * hw * 8 * ves < ((size_t)1 << 32) - 64 && hw < ((size_t)1 << 29);
+           4 * (size_t)D * hw * 8 * ves + 48 * hw * 8 * ves < ((size_t)1 << 32) - 64 && hw < ((size_t)1 << 29);
 }
 
 // fp32 features [4][N][h][w][8], volume in `dtype`
