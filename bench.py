@@ -116,6 +116,16 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
             elif env.get("MVS_CONV_WINO") != "0":
                 for n in ("conv2", "conv4"):
                     ex[n]["flops"] = costs[n]["flops"] * 20.0 / 27.0
+            if env.get("MVS_TAIL_SPLIT") != "0" and env.get("MVS_FUSE_PROB") != "0":
+                # the fused tail (csrc/conv11_prob.hip, conv11_prob_split_kernel): conv11 with split operands on the bf16
+                # matrix cores -- six cross products, 9 (z, y)-tap combos in 10 k-slots, x parity folded into N (one of
+                # four (dx, px) blocks of the panel is zero): 6 x 10/9 x 4/3 = 8.9x its multiply-adds -- and the prob
+                # stencil as packed fp32 FMAs on the vector units: two units that can work side by side, so the
+                # compute floor is the larger of the two times
+                f11 = costs["conv11"]["flops"] * 6.0 * (10.0 / 9.0) * (4.0 / 3.0)
+                ex["conv11_prob"]["parts"] = [(f11, MFMA_16BIT_PEAK_TFLOPS), (costs["prob"]["flops"], MFMA_F32_PEAK_TFLOPS)]
+                ex["conv11_prob"]["flops"] = f11 + costs["prob"]["flops"]
+                ex["conv11_prob"]["arith"] = "conv11: 3xbf16 split operands, six cross products, fp32 accumulate; prob: fp32 vector FMAs"
     else:
         for n in ("prob", "conv11_prob", "softargmin"):
             ex[n]["bytes"] = costs[n]["bytes"] + V0 * 2
@@ -130,6 +140,14 @@ def conv0_split_enabled(env=None):
     return env.get("MVS_CONV0_SPLIT") != "0"
 
 
+def compute_floor_s(c_ex, mfma_peak):
+    """Seconds the executed arithmetic needs at the peak of the unit(s) it runs on: `parts` = [(flops, peak TFLOP/s)]
+    for a stage whose work sits on two units that can overlap (the larger time), else flops / the stage's peak."""
+    if "parts" in c_ex:
+        return max(f / (p * 1e12) for f, p in c_ex["parts"])
+    return c_ex["flops"] / (c_ex.get("mfma_peak", mfma_peak) * 1e12)
+
+
 def stage_entry(ms, c_alg, c_ex, mfma_peak):
     """One `stages` entry: measured ms, the rates, and two roofline fractions -- `frac` from what the kernel really
     executes / moves (<= 1 by construction), `frac_algorithmic` from SURVEY d3's algorithmic bytes / FLOPs (a Winograd
@@ -140,7 +158,7 @@ def stage_entry(ms, c_alg, c_ex, mfma_peak):
     ent["GBps"] = round(c_alg["bytes"] / ms / 1e6, 1)
     if c_alg["flops"]:
         ent["TFLOPs"] = round(c_alg["flops"] / ms / 1e9, 2)
-    t_hbm, t_mfma = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e6), c_ex["flops"] / (c_ex.get("mfma_peak", mfma_peak) * 1e9)
+    t_hbm, t_mfma = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e6), compute_floor_s(c_ex, mfma_peak) * 1e3
     ent["bound"] = "mfma" if t_mfma > t_hbm else "hbm"
     ent["frac"] = round(max(t_hbm, t_mfma) / ms, 3)
     if "arith" in c_ex:
@@ -156,7 +174,7 @@ def roofline_entry(dom, ms, c_alg, c_ex, mfma_peak):
     `algorithmic_ratio` (not a fraction of peak: > 1 is possible for a Winograd kernel)."""
     t_hbm = c_ex["bytes"] / (HBM_PEAK_GBPS * 1e9)
     ex_peak = c_ex.get("mfma_peak", mfma_peak)     # peak of the matrix unit the kernel really runs on
-    t_mfma = c_ex["flops"] / (ex_peak * 1e12)
+    t_mfma = compute_floor_s(c_ex, mfma_peak) if "parts" not in c_ex else 0.0   # a two-unit stage is priced on its bytes here
     if t_mfma > t_hbm:
         ach, alg = c_ex["flops"] / ms / 1e9, c_alg["flops"] / ms / 1e9
         r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": ex_peak, "unit": "TFLOP/s",
@@ -521,8 +539,8 @@ def measure(ctx, config, storage, K, Wm, prewarm_ms, S, KS, staged_timed=False):
     # ran; the executed floor prices what this build's kernels really issue / move (fused tail counted once)
     path_bytes, path_flops, stagewise_floor_s = path_totals(costs, mfma_peak)
     ran = [n for n in stage_names if n in ex_costs]
-    executed_floor_s = sum(max(ex_costs[n]["bytes"] / (HBM_PEAK_GBPS * 1e9),
-                               ex_costs[n]["flops"] / (ex_costs[n].get("mfma_peak", mfma_peak) * 1e12)) for n in ran)
+    executed_floor_s = sum(max(ex_costs[n]["bytes"] / (HBM_PEAK_GBPS * 1e9), compute_floor_s(ex_costs[n], mfma_peak))
+                           for n in ran)
     res = dict(config=config, storage=storage, N=N, D=D, h=h, w=w, H=cfg["H"], W=cfg["W"], K=K, Wm=Wm, S=S, KS=KS,
                elapsed=elapsed, first_elapsed=first_elapsed, effective_warmup=effective_warmup,
                maps_per_s=world * K / elapsed, ms_per_step=elapsed / K * 1e3, per_rank=list(per_rank),

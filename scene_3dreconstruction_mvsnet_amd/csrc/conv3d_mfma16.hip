@@ -19,6 +19,7 @@
 
 #include "mvs_internal.h"
 #include "storage.h"
+#include "split_ops.h"
 
 namespace mvs {
 
@@ -1056,31 +1057,6 @@ int launch_layer_mfma16(int layer, const void* x, const void* skip, void* y, con
 // layout of the 16-bit kernels: pack_split_panels).
 //   convgs   : conv2 .. conv4 (the tile scheme of convg16)
 // =============================================================================================
-typedef float g_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ g_f32x2 gs_stage(const g_f32x2 a, unsigned& packed) {   // packed = bf16x2(a) RNE; returns a - packed
-    const g_bf16x2 h = __builtin_convertvector(a, g_bf16x2);
-    packed = __builtin_bit_cast(unsigned, h);
-    const g_f32x2 w = {__uint_as_float(packed << 16), __uint_as_float(packed & 0xFFFF0000u)};
-    return a - w;
-}
-// 8 fp32 channels of one voxel -> three 16-byte bf16 fragments
-__device__ __forceinline__ void gs_split8(const f32x4 lo, const f32x4 hi, u32x4& p1, u32x4& p2, u32x4& p3) {
-    const g_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned a, b;
-        const g_f32x2 r1 = gs_stage(v[j], a);
-        const g_f32x2 r2 = gs_stage(r1, b);
-        p1[j] = a;
-        p2[j] = b;
-        p3[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, g_bf16x2));
-    }
-}
-__device__ __forceinline__ f32x4 gs_mfma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 template <int CIN, int COUT, int S, int BZ, int BY, int BX>
 __global__ __launch_bounds__(256) void convgs_mfma_kernel(
     const float* __restrict__ x,              // [CIN/8][Di][Hi][Wi][8] fp32

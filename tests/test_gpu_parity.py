@@ -320,6 +320,7 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_CONV0_SPLIT": "2"},    # the split-operand conv0 in its first form (one tile per 4-wave block)
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
+    {"MVS_TAIL_SPLIT": "0"},     # the fused tail's transposed convolution on the fp32 MFMA (conv11_prob_priv)
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each

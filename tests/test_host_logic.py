@@ -111,6 +111,8 @@ def test_pack_weights_folds_bn_and_relayouts():
             ci, co = layer_ch[l]
             elems = 4 * 9 * 64 * 8 if l == 0 else (ci // 8) * (co // 16) * 7 * 64 * 8 if l <= 6 \
                 else (ci // 8) * (2 * co // 16) * 5 * 64 * 8
+            if l == 9 and npdt == "bf16":
+                h16_bf16_off9 = off
             if l == 2:
                 panel = blob[off:off + elems // 2].view(np.uint16).reshape(ci // 8, co // 16, 7, 64, 8)
                 wl = blob[woffs[l]:woffs[l] + 27 * ci * co].reshape(27, ci, co)
@@ -175,6 +177,16 @@ def test_pack_weights_folds_bn_and_relayouts():
         assert np.all(np.abs(f[1]) <= 2.0 ** -8 * np.abs(f[0]) + 1e-30) and np.all(np.abs(f[2]) <= 2.0 ** -16 * np.abs(f[0]) + 1e-30)
         assert (f[0] != 0).mean() > 0.5
         off += ((3 * elems) // 2 + 63) // 64 * 64
+    # the same for conv11 (layer 9, the fused tail's transposed convolution): [3 pieces][2 chunks][5 k-steps][64][8];
+    # piece 0 is the layer's bf16 panel of the 16-bit modes
+    elems = 2 * 1 * 5 * 64 * 8
+    pcs = blob[off:off + (3 * elems) // 2].view(np.uint16).reshape(3, elems)
+    f = (pcs.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.all(np.abs(f[1]) <= 2.0 ** -8 * np.abs(f[0]) + 1e-30) and np.all(np.abs(f[2]) <= 2.0 ** -16 * np.abs(f[0]) + 1e-30)
+    assert (f[0] != 0).mean() > 0.5
+    h9 = blob[h16_bf16_off9:h16_bf16_off9 + elems // 2].view(np.uint16)
+    assert np.array_equal(h9, pcs[0])
+    off += ((3 * elems) // 2 + 63) // 64 * 64
     assert off * 4 == _lib.query_weights_blob()
 
 
@@ -507,6 +519,14 @@ def test_bench_roofline_fractions_never_exceed_one():
     assert ex["conv1"] == costs["conv1"] and ex["conv0"]["bytes"] == costs["conv0"]["bytes"]
     assert exs["conv1"] == costs["conv1"]      # conv1 stays on the fp32-MFMA z-marching kernel
     assert bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_CONV0_WINO": "0"})["conv0"]["flops"] == costs["conv0"]["flops"]
+    # the fused tail: conv11 with split operands on the bf16 matrix cores beside the prob stencil on the vector units --
+    # its floor is the bytes (173 MB), not the sum of the two compute times; MVS_TAIL_SPLIT=0: all on the fp32 units
+    et = bench.stage_entry(0.092, costs["conv11_prob"], exs["conv11_prob"], bench.mfma_peak_tflops("f32"))
+    assert "parts" in exs["conv11_prob"] and et["bound"] == "hbm" and 0.2 < et["frac"] < 0.3 and "split" in et["arith"]
+    e0 = bench.executed_costs(costs, "f32", N, D, h, w, env={"MVS_TAIL_SPLIT": "0"})["conv11_prob"]
+    assert e0 == costs["conv11_prob"]
+    et0 = bench.stage_entry(0.103, costs["conv11_prob"], e0, bench.mfma_peak_tflops("f32"))
+    assert et0["bound"] == "mfma" and 0.25 < et0["frac"] < 0.4
     # round 3's driver line: conv0 0.3441 ms -> algorithmic 1.0043 of the fp32 MFMA peak, executed 0.502
     peak = bench.mfma_peak_tflops("f32")
     ent = bench.stage_entry(0.3441, costs["conv0"], ex["conv0"], peak)

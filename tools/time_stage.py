@@ -29,13 +29,18 @@ if what == "conv0z":   # all-zero input: same instruction stream, idle data path
 
 
 def run():
-    if what in ("warp", "warpz"):
+    if what == "tail":
+        _lib.conv11_prob(t8, t0, blob)
+    elif what in ("warp", "warpz"):
         _lib.warp_variance(feats, rt, dv, ws)
     else:
         _lib.conv_layer(layer, var if layer == 0 else x_in, None, blob)
 
 
 x_in = None
+if what == "tail":   # conv11 + skip + prob on random inputs of the cfg2 shapes
+    t8 = torch.randn((2, D // 2, h // 2, w // 2, 8), device=dev)
+    t0 = torch.randn((1, D, h, w, 8), device=dev)
 if layer == 10:
     x_in = torch.randn((1, D, h, w, 8), device=dev)
 elif layer in (1, 2):
