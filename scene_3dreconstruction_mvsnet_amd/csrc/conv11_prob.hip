@@ -676,26 +676,28 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
     const float bv = bias[co];
     // element e of the accumulators: input voxel m = 4 g + e -> tile column 8 tx + (m & 7) = 8 tx + 4 (g & 1) + e
     const int sbase0 = (2 * (2 * ty + (g >> 1)) + 1) * RS + (co >> 2) * HS + (2 * (8 * tx + 4 * (g & 1)) + px + 1) * 4 + (co & 3);
-    // skip pieces of the wave's strip: lane -> column xx, half, row parity; j -> plane j >> 1, row 2 (j & 1) + parity
-    int srel[4], sl[2];
-    unsigned sok = 0;
+    // skip values in the ACCUMULATOR layout (element e of class (pz, py) <-> output voxel (2 i + pz, 2 row + py,
+    // 2 (column + e) + px), channel co): one dword per element, 16 lanes x 4 bytes = the two x-adjacent voxels of one
+    // input column; they are added in registers, so the tile is written once (the 16-byte read-modify-write of the
+    // first form cost 8 LDS operations per wave and step and a write -> read -> write latency chain in each scatter
+    // phase).  Raw buffer loads: a position beyond the volume's rows / columns reads a neighbour's value or, past the
+    // end of the tensor, zero -- it is masked when the tile is written.
+    const int srow = 2 * (iy0 + 2 * ty + (g >> 1)), scol = 2 * (ix0 + 8 * tx + 4 * (g & 1)) + px;   // py = 0, e = 0
+    const unsigned sbase = (unsigned)((((size_t)srow * Wo + scol) * 8 + co) * 4);
+    const bool vy0 = srow < Ho, vy1 = srow + 1 < Ho;
+    bool vx[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int xx = lane & 15, half = (lane >> 4) & 1, rr = 2 * (j & 1) + (lane >> 5), pz = j >> 1;
-        const int oy = 4 * ty + rr, ox = 16 * tx + xx;
-        const int gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
-        const bool ok = gy < Ho && gx < Wo;
-        srel[j] = ok ? (int)((((size_t)pz * Ho + gy) * Wo + gx) * 8 + half * 4) : 0;
-        sok |= ok ? (1u << j) : 0u;
-        if (j < 2) sl[j] = (oy + 1) * RS + half * HS + (ox + 1) * 4;
-    }
-    f32x4 sk[4];
-    auto load_skip = [&](int i, bool de, bool dodd) {
-        const size_t base = (size_t)(2 * i) * HWo * 8;
+    for (int e = 0; e < 4; ++e) vx[e] = scol + 2 * e < Wo;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(skip), (short)0, (int)((size_t)Do * HWo * 32), 0x00020000);
+    float sk[4][4];
+    auto load_skip = [&](int i) {   // planes 2 i, 2 i + 1
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = ((sok >> j) & 1u) && ((j >> 1) ? dodd : de);
-            sk[j] = *reinterpret_cast<const f32x4*>(skip + (ok ? base + srel[j] : (size_t)0));   // masked when added
+        for (int c = 0; c < 4; ++c) {
+            const unsigned so = (unsigned)((((size_t)(2 * i + (c >> 1)) * Ho + (c & 1)) * Wo) * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sk[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, (int)(sbase + 64 * e), (int)so, 0));
         }
     };
     const g_u32x4* bsrc = reinterpret_cast<const g_u32x4*>(bpan) + lane;
@@ -731,8 +733,8 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
             acc[cls] = gs_mfma(a1, b1, acc[cls]);
         }
     };
-    // conv11 plane pz of this step -> the tile: ReLU(acc + bias) scattered, then the skip values added 16 bytes at a time
-    auto scatter = [&](int pz, const f32x4& s0, const f32x4& s1) {   // s0, s1: the sums of classes (pz, py = 0 / 1)
+    // conv11 plane pz of this step -> the tile: ReLU(sum + bias) + skip, zero beyond the volume (the prob layer's padding)
+    auto scatter = [&](int pz, const f32x4& s0, const f32x4& s1) {   // s0, s1: the sums of classes (pz, py = 0 / 1), bias included
 #if MVS_ABLATE == 84
         return;
 #endif
@@ -740,16 +742,11 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
         for (int c = 0; c < 2; ++c) {
             float* dst = ct + c * RS + sbase0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[8 * e] = fmaxf((c ? s1 : s0)[e] + bv, 0.0f);
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf((c ? s1 : s0)[e], 0.0f) + sk[2 * pz + c][e];
+                dst[8 * e] = ((c ? vy1 : vy0) && vx[e]) ? v : 0.0f;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 t[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) t[j] = *reinterpret_cast<const f32x4*>(ct + sl[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            *reinterpret_cast<f32x4*>(ct + sl[j]) =
-                ((sok >> (2 * pz + j)) & 1u) ? t[j] + sk[2 * pz + j] : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
 
     // ---- stencil roles: thread -> one position of the 16 x 32 tile ----
@@ -806,7 +803,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
     // waits in front of store_a() are then COUNTED vmcnt on both paths into the loop
     load_a(i_first, 0);
     __builtin_amdgcn_sched_barrier(0);
-    load_skip(i_first, i_first >= za, i_first < zb);
+    load_skip(i_first);
     __syncthreads();
 
     // (sched_barrier: hipcc otherwise hoists the next loads above the use of the previous ones, into fresh registers,
@@ -824,7 +821,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
         const bool de = i >= za, dodd = i < zb;       // even / odd conv11 plane of this step wanted
         stage(i, 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){bv, bv, bv, bv};   // the bias (a lane's four elements share co)
         mfma_chunk(0);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -837,7 +834,7 @@ __global__ __launch_bounds__(512, 4) void conv11_prob_split_kernel(
         A = fresh;
         SPLIT_SYNC_B();
         if (dodd) scatter(1, acc[2], acc[3]);
-        load_skip(min(i + 1, i_last), true, i + 1 < zb);   // unconditional
+        load_skip(min(i + 1, i_last));                // unconditional
         SPLIT_SYNC_B();
         if (dodd) stencil(B, C, A);            // odd plane 2i + 1: completes logit 2i
         emit(2 * i, B, dodd && de);
@@ -902,7 +899,8 @@ int launch_conv11_prob(const void* x, const void* skip, float* cost, const float
     if (ZC > Di) ZC = Di;
     const int nzc = (Di + ZC - 1) / ZC;
     const dim3 grid(nbx * nby * nzc);
-    if (dtype == MVS_F32 && tail_split_enabled()) {
+    // the split-operand kernel addresses the skip tensor through a buffer descriptor (32-bit byte offsets)
+    if (dtype == MVS_F32 && tail_split_enabled() && (size_t)Di * Hi * Wi * 256 < ((size_t)1 << 32)) {
         conv11_prob_split_kernel<<<grid, 512, 0, s>>>(
             static_cast<const float*>(x), reinterpret_cast<const unsigned short*>(blob + L.s16_off[9]), blob + L.b_off[9],
             static_cast<const float*>(skip), blob + L.w_off[10], blob + L.b_off[10], cost, Di, Hi, Wi, ZC, nbx, nby);
