@@ -116,6 +116,14 @@ def executed_costs(costs, storage, N, D, h, w, env=None):
             elif env.get("MVS_CONV_WINO") != "0":
                 for n in ("conv2", "conv4"):
                     ex[n]["flops"] = costs[n]["flops"] * 20.0 / 27.0
+            sd = int(env.get("MVS_SPLIT_DECONV", "2"))
+            for bit, n in ((1, "conv7"), (2, "conv9")):
+                if sd & bit:
+                    # transposed layers with split operands (csrc/conv3d_mfma16.hip deconvgs): six cross products,
+                    # 9 (z, y)-tap combos in 10 k-slots, x parity folded into N (a quarter of the panel is zero)
+                    ex[n]["flops"] = costs[n]["flops"] * 6.0 * (10.0 / 9.0) * (4.0 / 3.0)
+                    ex[n]["mfma_peak"] = MFMA_16BIT_PEAK_TFLOPS
+                    ex[n]["arith"] = "3xbf16 split operands, six cross products, fp32 accumulate"
             if env.get("MVS_TAIL_SPLIT") != "0" and env.get("MVS_FUSE_PROB") != "0":
                 # the fused tail (csrc/conv11_prob.hip, conv11_prob_split_kernel): conv11 with split operands on the bf16
                 # matrix cores -- six cross products, 9 (z, y)-tap combos in 10 k-slots, x parity folded into N (one of
@@ -741,7 +749,7 @@ def main(argv=None):
             "warmup": Wm, "effective_warmup_steps": res["effective_warmup"],
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (conv0, conv2-4: 3xbf16 split operands on the bf16 matrix cores, fp32 accumulate)"
+            "dtype": ("f32 (conv0, conv2-4, conv9, conv11: 3xbf16 split operands on the bf16 matrix cores, fp32 accumulate)"
                       if conv0_split and os.environ.get("MVS_SPLIT_LAYERS") != "0" else
                       "f32 (conv0: 3xbf16 split operands, fp32 accumulate)" if conv0_split else "f32") if storage == "f32" else (
                 f"{storage} storage, f32 MFMA arithmetic" if os.environ.get("MVS_MFMA16") == "0"

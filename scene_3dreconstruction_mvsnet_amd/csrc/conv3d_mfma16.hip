@@ -1207,20 +1207,193 @@ static int run_convgs(const void* x, void* y, const unsigned short* bp, const fl
     return check_hip(hipGetLastError(), "convgs_mfma launch");
 }
 
+// deconvgs: the transposed layers conv7 / conv9 (+ skip) for fp32 volumes with split operands -- deconvg16's tile scheme
+// and tap order (deconv16_tap: 5 k-steps per 8-channel chunk, 4 (pz, py) classes, x parity folded into N), fp32 in / out,
+// three bf16 tiles, three panels (pack_split_panels), six MFMAs per k-step with the small terms first.
+template <int CIN, int COUT, int BZ, int BY, int BX>
+__global__ __launch_bounds__(256) void deconvgs_mfma_kernel(
+    const float* __restrict__ x,              // [CIN/8][Di][Hi][Wi][8] fp32
+    const unsigned short* __restrict__ bp,    // [3 pieces][NCH][NTT][5][64][8] bf16
+    const float* __restrict__ bias,           // [COUT]
+    const float* __restrict__ skip,           // [COUT/8][2 Di][2 Hi][2 Wi][8] fp32
+    float* __restrict__ y, int Di, int Hi, int Wi) {
+    using G = DeconvG16<CIN, COUT, BZ, BY, BX>;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[3 * G::TILE_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave % G::NTT, mg = wave / G::NTT;
+    const int nbx = (Wi + 8 * BX - 1) / (8 * BX), nby = (Hi + 2 * BY - 1) / (2 * BY);
+    int b = blockIdx.x;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby;
+    const int bz = b / nby;
+    const int ix0 = bx * 8 * BX, iy0 = by * 2 * BY, iz0 = bz * BZ;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t Vin = (size_t)Di * Hi * Wi, Vout = Vin * 8;
+    constexpr size_t PANEL = (size_t)G::NCH * G::NTT * G::KS * 64;   // u32x4 fragments per piece
+
+    // staging: piece p = tid + i * 256 = one voxel (8 channels) of the halo tile; threads beyond the tile shadow its
+    // last voxel (no branch in the staging code)
+    int goff[G::PPT], loff[G::PPT];
+    unsigned inside = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPT; ++i) {
+        const int v = min(tid + i * 256, G::NPIECE - 1);
+        const int hx = v % G::HX, t = v / G::HX;
+        const int hy = t % G::HY, hz = t / G::HY;
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        const bool ok = gz < Di && gy < Hi && gx < Wi;
+        goff[i] = ok ? (int)((((size_t)gz * Hi + gy) * Wi + gx) * 8) : 0;
+        inside |= ok ? (1u << i) : 0u;
+        loff[i] = ((hz * G::HY + hy) * G::HXP + hx) * G::VS;
+    }
+
+    const int r = lane & 15, g = lane >> 4;
+    const int ry = r >> 3, rx = r & 7;
+    int abase[G::MPW];
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        abase[i] = ((tz * G::HY + 2 * ty + ry) * G::HXP + 8 * tx + rx + (g & 1)) * G::VS;
+    }
+    int koff[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        const Deconv16Tap t0 = deconv16_tap(ks, 0), t1 = deconv16_tap(ks, 1);
+        koff[ks] = (g >> 1) ? (t1.dz * G::HY + t1.dy) * G::HXP * G::VS : (t0.dz * G::HY + t0.dy) * G::HXP * G::VS;
+    }
+
+    f32x4 acc[4][G::MPW];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < G::MPW; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 breg[3][G::KS];
+    f32x4 stg[G::PPT][2];
+
+    auto load_b = [&](int c) {
+        const u32x4* bsrc = reinterpret_cast<const u32x4*>(bp) + ((size_t)(c * G::NTT + nt) * G::KS) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) breg[q][ks] = bsrc[q * PANEL + ks * 64];
+    };
+    auto load_a = [&](int c) {
+        const float* plane = x + (size_t)c * Vin * 8;
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) {
+            stg[i][0] = *reinterpret_cast<const f32x4*>(plane + goff[i]);
+            stg[i][1] = *reinterpret_cast<const f32x4*>(plane + goff[i] + 4);
+        }
+    };
+    auto store_a = [&]() {
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < G::PPT; ++i) {
+            const bool in = (inside >> i) & 1u;
+            u32x4 p1, p2, p3;
+            gs_split8(in ? stg[i][0] : z4, in ? stg[i][1] : z4, p1, p2, p3);
+            *reinterpret_cast<u32x4*>(tile + loff[i]) = p1;
+            *reinterpret_cast<u32x4*>(tile + G::TILE_ELEMS + loff[i]) = p2;
+            *reinterpret_cast<u32x4*>(tile + 2 * G::TILE_ELEMS + loff[i]) = p3;
+        }
+    };
+
+    load_b(0);
+    load_a(0);
+    store_a();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < G::NCH; ++c) {
+        if (c + 1 < G::NCH) load_a(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const int cls = deconv16_tap(ks, 0).cls;
+#pragma unroll
+            for (int i = 0; i < G::MPW; ++i) {
+                const unsigned short* ap = tile + abase[i] + koff[ks];
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(ap);
+                const u32x4 a2 = *reinterpret_cast<const u32x4*>(ap + G::TILE_ELEMS);
+                const u32x4 a3 = *reinterpret_cast<const u32x4*>(ap + 2 * G::TILE_ELEMS);
+                acc[cls][i] = gs_mfma(a3, breg[0][ks], acc[cls][i]);   // the small terms first
+                acc[cls][i] = gs_mfma(a1, breg[2][ks], acc[cls][i]);
+                acc[cls][i] = gs_mfma(a2, breg[1][ks], acc[cls][i]);
+                acc[cls][i] = gs_mfma(a2, breg[0][ks], acc[cls][i]);
+                acc[cls][i] = gs_mfma(a1, breg[1][ks], acc[cls][i]);
+                acc[cls][i] = gs_mfma(a1, breg[0][ks], acc[cls][i]);
+            }
+        }
+        if (c + 1 < G::NCH) {
+            load_b(c + 1);
+            __syncthreads();
+            store_a();
+            __syncthreads();
+        }
+    }
+
+    const int nn = 16 * nt + (lane & 15);
+    const int px = nn / COUT, co = nn % COUT;
+    const float bv = bias[co];
+    const size_t plane_off = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+#pragma unroll
+    for (int i = 0; i < G::MPW; ++i) {
+        const int t = mg * G::MPW + i;
+        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+        const int gz = iz0 + tz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * (lane >> 4) + e;
+            const int gy = iy0 + 2 * ty + (m >> 3), gx = ix0 + 8 * tx + (m & 7);
+            if (gz < Di && gy < Hi && gx < Wi) {
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
+                    const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
+                    y[o] = fmaxf(acc[cls][i][e] + bv, 0.0f) + skip[o];
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int BZ, int BY, int BX>
+static int run_deconvgs(const void* x, const void* skip, void* y, const unsigned short* bp, const float* bias,
+                        int Di, int Hi, int Wi, hipStream_t s) {
+    if ((size_t)Di * Hi * Wi * 8 >= ((size_t)1 << 31))
+        return fail(MVS_ERR_BAD_SHAPE, "deconvgs_mfma: plane exceeds 31-bit offsets");
+    const int nb = ((Wi + 8 * BX - 1) / (8 * BX)) * ((Hi + 2 * BY - 1) / (2 * BY)) * ((Di + BZ - 1) / BZ);
+    deconvgs_mfma_kernel<CIN, COUT, BZ, BY, BX><<<nb, 256, 0, s>>>(static_cast<const float*>(x), bp, bias,
+                                                                   static_cast<const float*>(skip),
+                                                                   static_cast<float*>(y), Di, Hi, Wi);
+    return check_hip(hipGetLastError(), "deconvgs_mfma launch");
+}
+
 // fp32 volumes, split operands: conv2, conv3, conv4 (measured at cfg2 against the fp32-MFMA kernels: 0.0588 -> 0.0534,
 // 0.0310 -> 0.0276, 0.0396 -> 0.0329 ms).  Measured and NOT selected: conv5 / conv6 on this tile kernel (0.0182 / 0.0289
 // against 0.0176 / 0.0242 ms for the all-K-resident split-K fp32 kernels: on 7,680 voxels the chunk pipeline is the cost,
 // not the matrix pipe), conv1 on it (0.083 ms) and as a z-marching kernel with three bf16 rings (attic/conv1_split_zmarch.hip:
 // 0.054 against 0.046 ms for the fp32-MFMA z-marching kernel)
-bool split_layer_covers(int layer) { return layer >= 2 && layer <= 4; }
+// conv9 likewise (deconvgs<32, 16, 2, 4, 1>: 0.0354 -> 0.0266 ms at cfg2; tiles of 1x4x1 / 2x2x1 / 1x2x2 / 1x2x1 M-tiles per
+// block: 0.0278 / 0.0277 / 0.0301 / 0.0316); conv7 on the same kernel measured 0.0248 against 0.0234 ms for the split-K
+// fp32 kernel and is not selected.
+bool split_layer_covers(int layer) {
+    static const int deconv = [] {   // MVS_SPLIT_DECONV: bit 0 = conv7, bit 1 = conv9; default 2
+        const char* e = getenv("MVS_SPLIT_DECONV");
+        return e ? atoi(e) : 2;
+    }();
+    return (layer >= 2 && layer <= 4) || (layer == 7 && (deconv & 1)) || (layer == 8 && (deconv & 2));
+}
 int launch_layer_split(int layer, const void* x, const void* skip, void* y, const void* panel, const float* bias,
                        int Di, int Hi, int Wi, hipStream_t s) {
     const unsigned short* bp = static_cast<const unsigned short*>(panel);
-    (void)skip;
     switch (layer) {
         case 2: return run_convgs<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 3: return run_convgs<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 4: return run_convgs<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 7: return run_deconvgs<64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 8: return run_deconvgs<32, 16, 2, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "split kernels: layer %d not covered", layer);
     }
 }

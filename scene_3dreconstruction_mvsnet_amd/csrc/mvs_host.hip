@@ -123,7 +123,7 @@ int mvs_pack_weights(const float* const* conv_weights, const float* const* bn_pa
     pack_conv0_wino43_weights(blob + L.w_off[0], blob + L.c0w43_off);
     pack_conv0_wino43_split_weights(blob + L.w_off[0], blob + L.c0w43s_off);
     for (int l = 2; l <= 4; ++l) pack_split_panels(l, blob + L.w_off[l], blob + L.s16_off[l]);
-    pack_split_panels(9, blob + L.w_off[9], blob + L.s16_off[9]);
+    for (int l = 7; l <= 9; ++l) pack_split_panels(l, blob + L.w_off[l], blob + L.s16_off[l]);
     for (int l = 2; l <= 4; l += 2)
         pack_convwz_weights(blob + L.w_off[l], kLayers[l].cin, kLayers[l].cout, blob + L.wz_off[l]);
     for (int l = 1; l <= 6; ++l)

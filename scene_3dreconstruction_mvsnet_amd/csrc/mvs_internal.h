@@ -45,7 +45,7 @@ struct BlobLayout {
     size_t wz_off[MVS_NUM_LAYERS]; // Winograd-z panels of the stride-1 layers 2 and 4 (conv_winograd.hip)
     size_t c0w43_off;              // conv0 Winograd F(4,3)-z panel [4][6][9][2][2][4][4] (conv_winograd.hip)
     size_t c0w43s_off;             // the same weights as three bf16 pieces, Toeplitz panel [4][6][3][3][64][8] (conv0_split.hip)
-    size_t s16_off[10];            // split-operand panels of layers 2..4 (conv3d_mfma16.hip) and 9 (conv11_prob.hip): three bf16 pieces in the h16 layout
+    size_t s16_off[10];            // split-operand panels of layers 2..4, 7, 8 (conv3d_mfma16.hip) and 9 (conv11_prob.hip): three bf16 pieces in the h16 layout
     size_t total_floats;
 };
 inline BlobLayout blob_layout() {
@@ -90,9 +90,9 @@ inline BlobLayout blob_layout() {
         L.s16_off[l] = off;
         off += (3 * elems / 2 + 63) & ~(size_t)63;
     }
-    {
-        const size_t elems = (size_t)(kLayers[9].cin / 8) * (2 * kLayers[9].cout / 16) * 5 * 64 * 8;
-        L.s16_off[9] = off;
+    for (int l = 9; l >= 7; --l) {   // conv11 first: the offsets of round 4's earlier builds stay where they were
+        const size_t elems = (size_t)(kLayers[l].cin / 8) * (2 * kLayers[l].cout / 16) * 5 * 64 * 8;
+        L.s16_off[l] = off;
         off += (3 * elems / 2 + 63) & ~(size_t)63;
     }
     L.total_floats = off;

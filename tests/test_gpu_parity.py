@@ -321,6 +321,8 @@ def test_nonfinite_coordinates_give_nan_like_torch():
     {"MVS_FORCE_DIRECT": "1"},   # VALU direct convolutions for every layer
     {"MVS_FUSE_PROB": "0"},      # conv11 and prob as two launches
     {"MVS_TAIL_SPLIT": "0"},     # the fused tail's transposed convolution on the fp32 MFMA (conv11_prob_priv)
+    {"MVS_SPLIT_DECONV": "3"},   # conv7 too with split operands (deconvgs; default: conv9 only)
+    {"MVS_SPLIT_DECONV": "0"},   # conv7 / conv9 on the fp32 MFMA
 ])
 def test_optin_kernel_variants(env):
     """The non-default kernels stay parity-green (selection is read once per process, so each

@@ -187,6 +187,15 @@ def test_pack_weights_folds_bn_and_relayouts():
     h9 = blob[h16_bf16_off9:h16_bf16_off9 + elems // 2].view(np.uint16)
     assert np.array_equal(h9, pcs[0])
     off += ((3 * elems) // 2 + 63) // 64 * 64
+    # ... conv9 (layer 8) and conv7 (layer 7), the transposed layers' split-operand kernels (deconvgs)
+    for l in (8, 7):
+        ci, co = _lib._LAYER_CH[l]
+        elems = (ci // 8) * (2 * co // 16) * 5 * 64 * 8
+        pcs = blob[off:off + (3 * elems) // 2].view(np.uint16).reshape(3, elems)
+        f = (pcs.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        assert np.all(np.abs(f[1]) <= 2.0 ** -8 * np.abs(f[0]) + 1e-30) and np.all(np.abs(f[2]) <= 2.0 ** -16 * np.abs(f[0]) + 1e-30)
+        assert (f[0] != 0).mean() > 0.5
+        off += ((3 * elems) // 2 + 63) // 64 * 64
     assert off * 4 == _lib.query_weights_blob()
 
 
