@@ -1371,7 +1371,9 @@ static int run_deconvgs(const void* x, const void* skip, void* y, const unsigned
 }
 
 // fp32 volumes, split operands: conv2, conv3, conv4 (measured at cfg2 against the fp32-MFMA kernels: 0.0588 -> 0.0534,
-// 0.0310 -> 0.0276, 0.0396 -> 0.0329 ms).  Measured and NOT selected: conv5 / conv6 on this tile kernel (0.0182 / 0.0289
+// 0.0310 -> 0.0276, 0.0396 -> 0.0329 ms with the 16-bit kernels' block tiles; a sweep of 8-20 tiles per layer
+// (tools/gpu/tile_sweep.sh, BZ x BY x BX M-tiles of 2 x 8 outputs): conv3 1x2x2 -> 2x2x1 0.0275 -> 0.0238, conv4 1x2x2 ->
+// 4x2x1 0.0325 -> 0.0254 -- z-deep, x-narrow tiles re-use the halo planes --, conv2 stays at 2x4x2).  Measured and NOT selected: conv5 / conv6 on this tile kernel (0.0182 / 0.0289
 // against 0.0176 / 0.0242 ms for the all-K-resident split-K fp32 kernels: on 7,680 voxels the chunk pipeline is the cost,
 // not the matrix pipe), conv1 on it (0.083 ms) and as a z-marching kernel with three bf16 rings (attic/conv1_split_zmarch.hip:
 // 0.054 against 0.046 ms for the fp32-MFMA z-marching kernel)
@@ -1390,8 +1392,8 @@ int launch_layer_split(int layer, const void* x, const void* skip, void* y, cons
     const unsigned short* bp = static_cast<const unsigned short*>(panel);
     switch (layer) {
         case 2: return run_convgs<16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 3: return run_convgs<16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 4: return run_convgs<32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convgs<16, 32, 2, 2, 2, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 4: return run_convgs<32, 32, 1, 4, 2, 1>(x, y, bp, bias, Di, Hi, Wi, s);
         case 7: return run_deconvgs<64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         case 8: return run_deconvgs<32, 16, 2, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "split kernels: layer %d not covered", layer);
