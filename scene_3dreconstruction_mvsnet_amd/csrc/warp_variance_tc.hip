@@ -90,24 +90,15 @@ __device__ __forceinline__ int quad_bcast(int v, int lane) {
 // rounds of the 1,024 resident blocks).
 // ---------------------------------------------------------------------------------------------
 
-// v_pk_fma_f32 / v_pk_mul_f32 with ONE half of the weight pair `w` broadcast to both lanes (op_sel): two bilinear weights
-// share an aligned register pair.  Written as asm because hipcc turns every such splat back into a scalar splat, which
-// occupies an aligned PAIR per weight with the odd register wasted (8 instead of 4 VGPRs for the four weights of a view).
-__device__ __forceinline__ f32x2 pk_fma_wlo(f32x2 a, f32x2 w, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma_whi(f32x2 a, f32x2 w, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_mul_whi(f32x2 a, f32x2 w) {
-    f32x2 d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(w));
-    return d;
-}
+// Round 4 note (a dead end that cost correctness): v_pk_fma_f32 / v_pk_mul_f32 written as inline asm with op_sel so that
+// two bilinear weights share one aligned register pair (128 instead of 133 VGPRs: a fourth wave per SIMD for N = 5 in fp32,
+// -5 %).  Bit-identical to the plain kernel in every single-stream test -- and wrong now and then when a bf16-MFMA
+// kernel of ANOTHER stream ran on the same CUs: one 16-lane pass of one depth step off by ~1 % in a LOW result that read the
+// HIGH half of the weight pair (op_sel:[0,1,..]), 85 of 1,200 launches beside the split-operand tail
+// (tools/probes/pair_two_streams.py); not an aliasing of destination and weight (tied / early-clobber operands: no change),
+// not a missing wait state (s_nop in front: no change).  The blend below uses only the form hipcc itself emits (a scalar
+// splat = op_sel_hi:[1,0,1], both halves read the LOW source): 0 of 1,200.  tests/test_gpu_fullsize.py::
+// test_cfg2_two_maps_in_flight_are_bit_identical_to_one and test_two_host_threads_on_two_streams_share_one_module watch it.
 
 struct SampK {
     int key;                    // (o00 << 2) | (dy << 1) | dx : the view's clamped 2x2 cell
@@ -345,13 +336,11 @@ __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ fe
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const float w00 = quad_bcast(mw00, v), w01 = quad_bcast(mw01, v);
-            const float w10 = quad_bcast(mw10, v), w11 = quad_bcast(mw11, v);
-            const f32x2 P0 = {w00, w01}, P1 = {w10, w11};   // two weights per register pair (pk_*_wlo / _whi)
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
+            // one weight at a time, broadcast to both halves of a channel pair (hipcc folds the splat into
+            // op_sel_hi:[1,0,1] -- "both halves read the low source"); wv = a*w00 + (b*w01 + (c*w10 + e*w11)) -- the
+            // plain kernel's nesting, per component
+            auto tapv = [&](int t, int j) -> f32x2 {
                 const int hh = j >> 1, q = (j & 1) * 2;
-                f32x2 a, bb, c, e;
                 if constexpr (PK) {
                     auto widen = [](unsigned d) -> f32x2 {   // two 16-bit values of one dword -> fp32 (exact)
                         if constexpr (FDT == MVS_F16) {
@@ -362,17 +351,36 @@ __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ fe
                             return (f32x2){__uint_as_float(d << 16), __uint_as_float(d & 0xFFFF0000u)};
                         }
                     };
-                    a = widen(tapk[v][0][j]); bb = widen(tapk[v][1][j]); c = widen(tapk[v][2][j]); e = widen(tapk[v][3][j]);
+                    return widen(tapk[v][t][j]);
                 } else {
-                    a = (f32x2){tap[v][0][hh][q], tap[v][0][hh][q + 1]};
-                    bb = (f32x2){tap[v][1][hh][q], tap[v][1][hh][q + 1]};
-                    c = (f32x2){tap[v][2][hh][q], tap[v][2][hh][q + 1]};
-                    e = (f32x2){tap[v][3][hh][q], tap[v][3][hh][q + 1]};
+                    return (f32x2){tap[v][t][hh][q], tap[v][t][hh][q + 1]};
                 }
-                // a*w00 + (b*w01 + (c*w10 + e*w11)) -- the plain kernel's nesting, per component
-                const f32x2 wv = pk_fma_wlo(a, P0, pk_fma_whi(bb, P0, pk_fma_wlo(c, P1, pk_mul_whi(e, P1))));
-                S[j] = S[j] + wv;
-                Q[j] = __builtin_elementwise_fma(wv, wv, Q[j]);
+            };
+            f32x2 wv[NP];
+            {
+                const float w = quad_bcast(mw11, v);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wv[j] = tapv(3, j) * (f32x2){w, w};
+            }
+            {
+                const float w = quad_bcast(mw10, v);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wv[j] = __builtin_elementwise_fma(tapv(2, j), (f32x2){w, w}, wv[j]);
+            }
+            {
+                const float w = quad_bcast(mw01, v);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wv[j] = __builtin_elementwise_fma(tapv(1, j), (f32x2){w, w}, wv[j]);
+            }
+            {
+                const float w = quad_bcast(mw00, v);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wv[j] = __builtin_elementwise_fma(tapv(0, j), (f32x2){w, w}, wv[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                S[j] = S[j] + wv[j];
+                Q[j] = __builtin_elementwise_fma(wv[j], wv[j], Q[j]);
             }
         }
         // pin the sums here: without it hipcc sinks the blend below the re-gather branches, keeps the

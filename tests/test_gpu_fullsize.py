@@ -124,6 +124,52 @@ def test_cfg2_maps_match_the_reference_fixture(cfg2):
     assert_conf_close(conf.cpu().numpy(), fx["photometric_confidence"], fx["expected_index"], atol=5e-4)
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_cfg2_two_maps_in_flight_are_bit_identical_to_one(cfg2, storage):
+    """bench.py's `value` mode: two maps in flight on two HIP streams, each with its own workspace.  Every map must be
+    the single-stream map bit for bit -- kernels of one map run BESIDE kernels of the other on the same CUs.  (Round 4:
+    a packed-fp32 instruction of the warp kernel whose destination aliased its op_sel-swizzled weight operand gave a
+    wrong 16-lane pass now and then, and only beside a bf16-MFMA kernel of the other stream; single-stream parity
+    tests cannot see that.)  Two host threads, two different problems, the bench size."""
+    import threading
+    code = _lib.dtype_code(storage)
+    c = synthetic.CONFIGS["cfg2"]
+    N, h, w, D = c["nviews"], c["H"] // 4, c["W"] // 4, c["D"]
+    probs = [(cu(cfg2["feats"]), cu(cfg2["proj"]), cu(cfg2["dv"])),
+             (cu(synthetic.random_features(N, 32, h, w, seed=4)), cu(synthetic.cameras(N, h, w, yaw_deg=0.5)), cu(cfg2["dv"]))]
+
+    def run(i, ws):
+        depth = torch.empty((h, w), device=DEV)
+        conf = torch.empty_like(depth)
+        _lib.depth_infer(*probs[i], cfg2["blob"], ws, depth, conf, dtype=code)
+        return depth, conf
+
+    want = [run(i, _lib.alloc_workspace(N, 32, D, h, w, DEV, code)) for i in range(2)]
+    torch.cuda.synchronize()
+    got, errors = [[], []], []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(DEV)
+            with torch.cuda.stream(st):
+                ws = _lib.alloc_workspace(N, 32, D, h, w, DEV, code)
+                for _ in range(25):
+                    got[i].append(run(i, ws))
+            st.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    bad = [(i, j) for i in range(2) for j, (d, cf) in enumerate(got[i])
+           if not (torch.equal(d, want[i][0]) and torch.equal(cf, want[i][1]))]
+    assert not bad, f"{len(bad)} of 50 maps differ from the single-stream result: {bad[:8]}"
+
+
 def test_cfg2_fused_conv11_prob_matches_oracle(cfg2):
     """mvs_conv11_prob (conv11 + conv0 skip + prob in ONE kernel, the default tail of the fp32 path) on its own
     at the bench size: fed with the oracle's d9 and c0, compared with the oracle's logits
