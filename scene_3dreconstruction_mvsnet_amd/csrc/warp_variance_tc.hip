@@ -226,12 +226,14 @@ __device__ __forceinline__ float pair_pick(float v) { return __int_as_float(pair
 // PK = 1 (16-bit features, CPT = 4 only; experiment of round 4): the cached taps stay PACKED (8 instead of
 // 16 VGPRs per view) and are widened inside the blend at every step -- bit-identical results (widening is exact), fewer
 // registers (more resident waves), more vector instructions per step.  Measured: section 10 of DESIGN.md.
+// four waves per SIMD: the N = 5 fp32 kernel allocates 130 VGPRs when left alone and fits 128 without spills when asked to
+// (every other variant is below 128 anyway); `make ablate61`: no occupancy request, `ablate62`: five waves (spills)
 #if MVS_ABLATE == 61
-#define MVS_WARP_LB __launch_bounds__(256, 4)
+#define MVS_WARP_LB __launch_bounds__(256)
 #elif MVS_ABLATE == 62
 #define MVS_WARP_LB __launch_bounds__(256, 5)
 #else
-#define MVS_WARP_LB __launch_bounds__(256)
+#define MVS_WARP_LB __launch_bounds__(256, 4)
 #endif
 template <int DT, int FDT, int NV, int CPT, int NTS, int PAIR, int PK = 0>
 __global__ MVS_WARP_LB void warp_variance_tc2_kernel(const void* __restrict__ feats_p,   // [4][N][hw][8] FDT
