@@ -215,6 +215,20 @@ static int run_convg16(const void* x, void* y, const unsigned short* bp, const f
     return check_hip(hipGetLastError(), "convg16_mfma launch");
 }
 
+// does a grid of BZ x BY x BX M-tiles (2 x 8 outputs each) over the OUTPUT of a stride-S layer (S = 1 with the input
+// dims for the transposed layers) still give every CU a block and a half?
+static bool tile_fills_chip(int Di, int Hi, int Wi, int S, int BZ, int BY, int BX) {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n;
+    }();
+    const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
+    const long nb = (long)((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
+    return 2 * nb >= 3 * (long)cus;
+}
+
 template <int DT>
 static int launch_convg16_dt(int layer, const void* x, void* y, const unsigned short* bp, const float* bias,
                              int Di, int Hi, int Wi, hipStream_t s) {
@@ -222,9 +236,19 @@ static int launch_convg16_dt(int layer, const void* x, void* y, const unsigned s
         case 1: return run_convg16<DT, 8, 16, 2, 2, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 2: return run_convg16<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 3: return run_convg16<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 4: return run_convg16<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 5: return run_convg16<DT, 32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 6: return run_convg16<DT, 64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        // conv4 .. conv6: z-deep block tiles (halo planes re-used) wherever they still give every CU a block and a half --
+        // round-4 sweep, cfg3 bf16 (1600x1184x256): conv4 1x2x2 -> 4x2x1 0.0574 -> 0.0456 ms, conv5 1x1x1 -> 2x1x1 0.0296 -> 0.0236,
+        // conv6 1x1x1 -> 4x1x1 0.0479 -> 0.0243; cfg5 fp16 (640x512x192): conv4 0.0133 -> 0.0118, conv5 / conv6 keep 1x1x1
+        // (2x1x1 / 4x1x1 would leave 240 / 120 blocks for 256 CUs: 0.0104 / 0.0145 against 0.0106 / 0.0134)
+        case 4:
+            if (tile_fills_chip(Di, Hi, Wi, 1, 4, 2, 1)) return run_convg16<DT, 32, 32, 1, 4, 2, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+            return run_convg16<DT, 32, 32, 1, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 5:
+            if (tile_fills_chip(Di, Hi, Wi, 2, 2, 1, 1)) return run_convg16<DT, 32, 64, 2, 2, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+            return run_convg16<DT, 32, 64, 2, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 6:
+            if (tile_fills_chip(Di, Hi, Wi, 1, 4, 1, 1)) return run_convg16<DT, 64, 64, 1, 4, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
+            return run_convg16<DT, 64, 64, 1, 1, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "convg16_mfma: layer %d not covered", layer);
     }
 }
@@ -1031,8 +1055,14 @@ static int launch_layer16_dt(int layer, const void* x, const void* skip, void* y
     }
     if (layer <= 6) return launch_convg16_dt<DT>(layer, x, y, bp, bias, Di, Hi, Wi, s);
     switch (layer) {
-        case 7: return run_deconvg16<DT, 64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
-        case 8: return run_deconvg16<DT, 32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        // the same for the transposed layers (tiles over the INPUT grid): cfg3 conv7 1x1x1 -> 2x1x1 0.0486 -> 0.0389, conv9 1x4x1
+        // -> 4x2x1 0.1059 -> 0.1026; cfg5 conv9 0.0171 -> 0.0164, conv7 stays (2x1x1: 240 blocks)
+        case 7:
+            if (tile_fills_chip(Di, Hi, Wi, 1, 2, 1, 1)) return run_deconvg16<DT, 64, 32, 2, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+            return run_deconvg16<DT, 64, 32, 1, 1, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+        case 8:
+            if (tile_fills_chip(Di, Hi, Wi, 1, 4, 2, 1)) return run_deconvg16<DT, 32, 16, 4, 2, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
+            return run_deconvg16<DT, 32, 16, 1, 4, 1>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         case 9: return run_deconvg16<DT, 16, 8, 1, 4, 2>(x, skip, y, bp, bias, Di, Hi, Wi, s);
         default: return fail(MVS_ERR_BAD_SHAPE, "mfma16: layer %d not covered", layer);
     }
