@@ -410,6 +410,9 @@ __global__ __launch_bounds__(256) void conv0p16_mfma_kernel(
 #ifndef C0Z_TY
 #define C0Z_TY 8
 #endif
+#ifndef C0Z_CACHE_C
+#define C0Z_CACHE_C 4
+#endif
 namespace c0z {
 constexpr int TY = C0Z_TY, TX = 32, HY = TY + 2, HX = TX + 2;
 constexpr int CH = HY * HX * 8;                  // 16-bit elements of one chunk of one plane
@@ -515,6 +518,21 @@ __global__ __launch_bounds__(c0z::THREADS) void conv0z16_mfma_kernel(
     // register sets rotate (the loop is unrolled by three: a register copy would wait for the loads just issued).
     // The kernel moves 26 KB per step and CU, so what it needs is bytes in flight: at cfg3 two sets (and a branch-free
     // VMEM stream, below) gave 0.655-0.685 ms, three 0.579, four 0.577
+    // The kernel is bound by its LDS reads (round-4 counters at cfg3: LDS busy 64 % of the kernel's cycles, 36 ds_read_b128 for
+    // 36 MFMAs per wave and step).  Plane z + 1's fragments, read as kz = 2 of step z, are the kz = 1 fragments of step
+    // z + 1: those of the first CACHE_C chunks stay in registers (in place: kz = 1 has consumed a register before kz = 2
+    // refills it): 24 instead of 36 reads per step at CACHE_C = 4 (48 VGPRs, 250 in all, no spills).  Measured, cfg3 / cfg5:
+    // CACHE_C 0: 0.600-0.609 / 0.080-0.081 ms, 2: 0.592-0.595 / 0.079, 3: 0.590-0.594 / 0.078-0.080, 4: 0.588-0.589 / 0.078-0.079
+    // -- the reads were not what bounds it (2.4 GB in 0.59 ms = 4.1 TB/s).
+    constexpr int CACHE_C = C0Z_CACHE_C;
+    u32x4 fcache[CACHE_C > 0 ? CACHE_C : 1][3];
+    if (CACHE_C > 0) {   // plane za (the first step's kz = 1)
+        const unsigned short* pl = ring + ((za + 1) & (RING - 1)) * SLOT + aoff;
+#pragma unroll
+        for (int c = 0; c < CACHE_C; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) fcache[c][ky] = *reinterpret_cast<const u32x4*>(pl + c * CH + ky * HX * 8);
+    }
     auto step = [&](int z, u32x4 (&cur)[PPT], u32x4 (&nxt)[PPT]) {
         load_plane(z + 4, nxt);   // unconditional (the plane index is clamped): hipcc then keeps counted vmcnt waits
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -525,7 +543,13 @@ __global__ __launch_bounds__(c0z::THREADS) void conv0z16_mfma_kernel(
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const u32x4 a = *reinterpret_cast<const u32x4*>(pl + c * CH + ky * HX * 8);
+                    u32x4 a;
+                    if (kz == 1 && c < CACHE_C) {
+                        a = fcache[c][ky];
+                    } else {
+                        a = *reinterpret_cast<const u32x4*>(pl + c * CH + ky * HX * 8);
+                        if (kz == 2 && c < CACHE_C) fcache[c][ky] = a;
+                    }
                     acc = mfma16<DT>(a, breg[c][kz * 3 + ky], acc);
                 }
         }
