@@ -1,4 +1,5 @@
-# conv0z16 with the kz = 1 fragments of the first C chunks cached in registers (default C = 2; ablate90 / 93 / 94 = C 0 / 3 / 4):
+# conv0z16 with the kz = 1 fragments of the first C chunks cached in registers (record of the round-4 A/B: the default was
+# C = 2 at the time, libmvs_hip_ablate90 / 93 / 94 were builds with -DC0Z_CACHE_C=0 / 3 / 4 of conv3d_mfma16.hip; default now 4):
 # 16-bit parity (identical results by construction: same order), stage times at cfg3 / cfg5
 cd $GRAFT_REPO_ROOT
 C=$GRAFT_REPO_ROOT/scene_3dreconstruction_mvsnet_amd/csrc
