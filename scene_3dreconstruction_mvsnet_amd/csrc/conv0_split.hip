@@ -396,9 +396,15 @@ __global__ __launch_bounds__(512) void conv0_w43p_kernel(
     __shared__ __attribute__((aligned(16))) float ex[NT_PLANES * NPOS * EXS];
     __shared__ int org[c43p_MAXT][4];   // origins of this block's tiles (three runtime divisions each: once, not per step)
 
+#if MVS_ABLATE == 75   // consumers on two SIMDs, producers on the other two (waves w and w + 4 share a SIMD): physical waves
+                       // {0, 1, 4, 5} take the consumer roles 0..3, {2, 3, 6, 7} the producer roles 4..7
+    const int lane = threadIdx.x & 63, pw_ = threadIdx.x >> 6;
+    const int wave = ((pw_ & 2) << 1) | ((pw_ & 4) >> 1) | (pw_ & 1), tid = wave * 64 + lane;
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
     // (producers on the older wave half instead -- waves 0-3 win the issue arbitration -- measured the same: 0.2744 /
-    // 0.2750 vs 0.2735 / 0.2767 ms)
+    // 0.2750 vs 0.2735 / 0.2767 ms; `make ablate75`, consumers and producers on SEPARATE SIMD pairs: 0.284 vs 0.278 ms)
     const bool consumer = __builtin_amdgcn_readfirstlane(wave) < 4;   // wave-uniform by construction; tell the compiler
     const int nbx = (W + TX - 1) / TX, nby = (H + TY - 1) / TY;
     const int G = gridDim.x;
