@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """mvs_depth_infer (features resident -> depth, confidence) on two HIP streams from two host threads, two different
 problems: iterations whose maps are not bit-identical to the single-stream result, and which intermediate differs first.
-python3 tools/probes/path_two_streams.py [D h w] [reps]"""
+python3 tools/probes/path_two_streams.py [D h w] [reps] [f32|f16|bf16] [N]"""
 import os
 import sys
 import threading
@@ -14,7 +14,8 @@ from scene_3dreconstruction_mvsnet_amd import _lib, synthetic  # noqa: E402
 
 D, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (48, 32, 40)
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-N = 3
+code = _lib.dtype_code(sys.argv[5]) if len(sys.argv) > 5 else _lib.MVS_F32
+N = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 dev = torch.device("cuda:0")
 blob = _lib.pack_weights(synthetic.random_costreg_state(0)).to(dev)
 probs = []
@@ -29,11 +30,11 @@ def run(i, ws):
     feats, proj, dv = probs[i]
     depth = torch.empty((h, w), device=dev)
     conf = torch.empty_like(depth)
-    _lib.depth_infer(feats, proj, dv, blob, ws, depth, conf)
+    _lib.depth_infer(feats, proj, dv, blob, ws, depth, conf, dtype=code)
     return depth, conf, ws["cost"].clone() if isinstance(ws, dict) and "cost" in ws else None
 
 
-ws0 = [_lib.alloc_workspace(N, 32, D, h, w, dev) for _ in range(2)]
+ws0 = [_lib.alloc_workspace(N, 32, D, h, w, dev, code) for _ in range(2)]
 want = [run(i, ws0[i]) for i in range(2)]
 torch.cuda.synchronize()
 for rep in range(reps):
@@ -42,7 +43,7 @@ for rep in range(reps):
     def worker(i):
         st = torch.cuda.Stream(dev)
         with torch.cuda.stream(st):
-            ws = _lib.alloc_workspace(N, 32, D, h, w, dev)
+            ws = _lib.alloc_workspace(N, 32, D, h, w, dev, code)
             for _ in range(40):
                 got[i].append(run(i, ws))
         st.synchronize()
