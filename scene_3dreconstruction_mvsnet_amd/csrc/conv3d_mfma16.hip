@@ -1124,7 +1124,13 @@ __global__ __launch_bounds__(256) void convgs_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NT, mg = wave / G::NT;
     const int nbx = (Wo + 8 * BX - 1) / (8 * BX), nby = (Ho + 2 * BY - 1) / (2 * BY);
-    int b = blockIdx.x;
+    // blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD: speed only, never correctness): XCD k works
+    // through the k-th eighth of the (z, row, column) tile sequence, so that tiles sharing halo planes / rows meet in one L2
+    int b;
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
@@ -1277,7 +1283,13 @@ __global__ __launch_bounds__(256) void deconvgs_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NTT, mg = wave / G::NTT;
     const int nbx = (Wi + 8 * BX - 1) / (8 * BX), nby = (Hi + 2 * BY - 1) / (2 * BY);
-    int b = blockIdx.x;
+    // blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD: speed only, never correctness): XCD k works
+    // through the k-th eighth of the (z, row, column) tile sequence, so that tiles sharing halo planes / rows meet in one L2
+    int b;
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
