@@ -94,7 +94,11 @@ __global__ __launch_bounds__(256) void convg16_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NT, mg = wave / G::NT;
     const int nbx = (Wo + 8 * BX - 1) / (8 * BX), nby = (Ho + 2 * BY - 1) / (2 * BY);
-    int b = blockIdx.x;
+    int b;   // XCD-aware tile order (see convgs_mfma_kernel)
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
@@ -878,7 +882,11 @@ __global__ __launch_bounds__(256) void deconvg16_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NTT, mg = wave / G::NTT;
     const int nbx = (Wi + 8 * BX - 1) / (8 * BX), nby = (Hi + 2 * BY - 1) / (2 * BY);
-    int b = blockIdx.x;
+    int b;   // XCD-aware tile order (see convgs_mfma_kernel)
+    {
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, rem = gridDim.x & 7;
+        b = k * q + min(k, rem) + (blockIdx.x >> 3);
+    }
     const int bx = b % nbx; b /= nbx;
     const int by = b % nby;
     const int bz = b / nby;
