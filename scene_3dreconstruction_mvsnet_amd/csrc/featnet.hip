@@ -66,7 +66,17 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NT, mg = wave / G::NT;
     const int nbx = (Wo + 8 * BX - 1) / (8 * BX);
-    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, n = blockIdx.y;
+    // workgroups are dealt round-robin over the 8 XCDs in linear order (speed only, never correctness): XCD k works through
+    // the k-th eighth of the (image, row, column) tile sequence, so that tiles sharing halo rows meet in one L2
+    int bt, n;
+    {
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x, tot = gridDim.x * gridDim.y;
+        const int k = lin & 7, q = tot >> 3, rem = tot & 7;
+        const int b = k * q + min(k, rem) + (lin >> 3);
+        n = b / (int)gridDim.x;
+        bt = b - n * (int)gridDim.x;
+    }
+    const int bx = bt % nbx, by = bt / nbx;
     const int ox0 = bx * 8 * BX, oy0 = by * 2 * BY;
     const int ix0 = ox0 * S - G::PAD, iy0 = oy0 * S - G::PAD;
     const size_t HWi = (size_t)Hi * Wi, HWo = (size_t)Ho * Wo;
@@ -229,7 +239,17 @@ __global__ __launch_bounds__(256) void fconv01_fused_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbx = (W + 31) / 32;
-    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx, n = blockIdx.y;
+    // workgroups are dealt round-robin over the 8 XCDs in linear order (speed only, never correctness): XCD k works through
+    // the k-th eighth of the (image, row, column) tile sequence, so that tiles sharing halo rows meet in one L2
+    int bt, n;
+    {
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x, tot = gridDim.x * gridDim.y;
+        const int k = lin & 7, q = tot >> 3, rem = tot & 7;
+        const int b = k * q + min(k, rem) + (lin >> 3);
+        n = b / (int)gridDim.x;
+        bt = b - n * (int)gridDim.x;
+    }
+    const int bx = bt % nbx, by = bt / nbx;
     const int ox0 = bx * 32, oy0 = by * 8;
     const size_t HW = (size_t)H * W;
     const float* im = static_cast<const float*>(img_v) + (size_t)n * 3 * HW;
