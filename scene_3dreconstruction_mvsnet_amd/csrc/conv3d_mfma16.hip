@@ -1286,7 +1286,15 @@ __global__ __launch_bounds__(256) void deconvgs_mfma_kernel(
     const float* __restrict__ skip,           // [COUT/8][2 Di][2 Hi][2 Wi][8] fp32
     float* __restrict__ y, int Di, int Hi, int Wi) {
     using G = DeconvG16<CIN, COUT, BZ, BY, BX>;
-    __shared__ __attribute__((aligned(16))) unsigned short tile[3 * G::TILE_ELEMS];
+    // epilogue staging tile (deconvg_mfma's scheme): one z parity of the block's 2BZ x 4BY x 16BX output voxels x COUT channels,
+    // rows padded (16 floats per 8 voxels, row pitch = 16 mod 32) so that the accumulator scatter is conflict-free
+    constexpr int OY = 4 * BY, OX = 16 * BX;
+    constexpr int RP0 = OX * COUT + 16 * (OX / 8), RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
+    constexpr int OUT_FLOATS = BZ * OY * RP, NUNIT = BZ * OY * OX * (COUT / 8), UPT = (NUNIT + 255) / 256;
+    constexpr int LDS_BYTES = 3 * G::TILE_ELEMS * 2 > OUT_FLOATS * 4 ? 3 * G::TILE_ELEMS * 2 : OUT_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned short* tile = reinterpret_cast<unsigned short*>(lds_raw);
+    float* otile = reinterpret_cast<float*>(lds_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NTT, mg = wave / G::NTT;
@@ -1407,27 +1415,57 @@ __global__ __launch_bounds__(256) void deconvgs_mfma_kernel(
         }
     }
 
+    // epilogue: col n -> (px, co); row m -> input voxel of the tile; class -> (pz, py).  ReLU(acc + bias) is scattered into the
+    // LDS tile [oz][oy][ox][co]; then every thread owns whole voxels of one C8 plane (32 B) and does the skip add with 16-byte
+    // loads / stores that are contiguous across the wave (the scalar form: 4-byte stores in 32-byte runs and one exposed skip
+    // load per element).  Two passes, one per output z parity; the skip values of a pass are requested before its scatter.
+    const int Do = 2 * Di;
     const int nn = 16 * nt + (lane & 15);
     const int px = nn / COUT, co = nn % COUT;
     const float bv = bias[co];
-    const size_t plane_off = (size_t)(co >> 3) * Vout * 8 + (co & 7);
 #pragma unroll
-    for (int i = 0; i < G::MPW; ++i) {
-        const int t = mg * G::MPW + i;
-        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
-        const int gz = iz0 + tz;
+    for (int pz = 0; pz < 2; ++pz) {
+        size_t uo[UPT];
+        int usrc[UPT];
+        f32x4 sk0[UPT], sk1[UPT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = 4 * (lane >> 4) + e;
-            const int gy = iy0 + 2 * ty + (m >> 3), gx = ix0 + 8 * tx + (m & 7);
-            if (gz < Di && gy < Hi && gx < Wi) {
+        for (int j = 0; j < UPT; ++j) {
+            const int u = tid + j * 256;
+            const int ox = u % OX;
+            int t = u / OX;
+            const int oy = t % OY; t /= OY;
+            const int ozl = t % BZ, pl = t / BZ;
+            const int gz = 2 * (iz0 + ozl) + pz, gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
+            const bool ok = u < NUNIT && gz < Do && gy < Ho && gx < Wo;
+            usrc[j] = ok ? (ozl * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + pl * 8 : -1;
+            uo[j] = ok ? ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8 : 0;
+            sk0[j] = *reinterpret_cast<const f32x4*>(skip + uo[j]);
+            sk1[j] = *reinterpret_cast<const f32x4*>(skip + uo[j] + 4);
+        }
+        __syncthreads();  // input tiles (pass 0) / previous pass's staging tile fully consumed
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls) {
-                    const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
-                    const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
-                    y[o] = fmaxf(acc[cls][i][e] + bv, 0.0f) + skip[o];
-                }
+        for (int i = 0; i < G::MPW; ++i) {
+            const int t = mg * G::MPW + i;
+            const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * (lane >> 4) + e;
+                const int ly = 2 * ty + (m >> 3), lx = 8 * tx + (m & 7);  // input voxel inside the block tile
+                const int ox = 2 * lx + px;
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+                    otile[(tz * OY + 2 * ly + py) * RP + ox * COUT + (ox >> 3) * 16 + co] =
+                        fmaxf(acc[2 * pz + py][i][e] + bv, 0.0f);
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+            if (usrc[j] < 0) continue;
+            const float* src = otile + usrc[j];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            *reinterpret_cast<f32x4*>(y + uo[j]) = lo + sk0[j];
+            *reinterpret_cast<f32x4*>(y + uo[j] + 4) = hi + sk1[j];
         }
     }
 }

@@ -1,0 +1,12 @@
+# transposed split / 16-bit tile kernels with the LDS-staged epilogue (default lib) against the scalar epilogue
+# (libmvs_hip_ablate99.so = the build before): parity, stage times
+cd $GRAFT_REPO_ROOT
+C=$GRAFT_REPO_ROOT/scene_3dreconstruction_mvsnet_amd/csrc
+python tests/layer_check.py 16 24 40 f32 f16 bf16 > gpurun_out/de_layer_check.log 2>&1; echo "layer_check rc=$?"; tail -1 gpurun_out/de_layer_check.log
+MVS_SPLIT_DECONV=3 python tests/layer_check.py 24 40 56 > gpurun_out/de_layer_check2.log 2>&1; echo "layer_check2 rc=$?"; tail -1 gpurun_out/de_layer_check2.log
+python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k "every_layer_matches_oracle or cfg3 or cfg5" 2>&1 | tail -1
+for l in libmvs_hip.so libmvs_hip_ablate99.so libmvs_hip.so libmvs_hip_ablate99.so; do
+MVS_LIB_PATH=$C/$l python bench.py --streams 1 --steps 10 --prewarm-ms 100 --no-cpu-baseline --no-e2e --no-live-traffic > /tmp/b.json 2>/dev/null
+python -c "
+import json; d=json.load(open('/tmp/b.json')); print('$l', d['value'], {k: v['ms'] for k, v in d['stages'].items() if k in ('conv7','conv9')}, {k:(v['value'], v['stages_ms']['conv7'], v['stages_ms']['conv9']) for k,v in d['other_configs'].items()})"
+done
