@@ -876,7 +876,14 @@ __global__ __launch_bounds__(256) void deconvg16_mfma_kernel(
     const void* __restrict__ x, const unsigned short* __restrict__ bp, const float* __restrict__ bias,
     const void* __restrict__ skip, void* __restrict__ y, int Di, int Hi, int Wi) {
     using G = DeconvG16<CIN, COUT, BZ, BY, BX>;
-    __shared__ __attribute__((aligned(16))) unsigned short tile[G::TILE_ELEMS];
+    // epilogue staging tile (fp32; deconvg_mfma's scheme, see deconvgs_mfma_kernel): one z parity of the block's output
+    constexpr int OY = 4 * BY, OX = 16 * BX;
+    constexpr int RP0 = OX * COUT + 16 * (OX / 8), RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
+    constexpr int OUT_FLOATS = BZ * OY * RP, NUNIT = BZ * OY * OX * (COUT / 8), UPT = (NUNIT + 255) / 256;
+    constexpr int LDS_BYTES = G::TILE_ELEMS * 2 > OUT_FLOATS * 4 ? G::TILE_ELEMS * 2 : OUT_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned short* tile = reinterpret_cast<unsigned short*>(lds_raw);
+    float* otile = reinterpret_cast<float*>(lds_raw);
     const unsigned short* xs = static_cast<const unsigned short*>(x);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -982,27 +989,56 @@ __global__ __launch_bounds__(256) void deconvg16_mfma_kernel(
 #undef MVS_LOAD_A
 #undef MVS_STORE_A
 
+    // epilogue: ReLU(acc + bias) scattered into the LDS tile [oz][oy][ox][co] (fp32), then every thread owns whole voxels of one
+    // C8 plane (8 channels = 16 B of 16-bit storage): skip add with 16-byte loads / stores contiguous across the wave (the
+    // scalar form stored 2-byte elements).  Two passes, one per output z parity; a pass requests its skip values first.
+    const int Do = 2 * Di;
     const int nn = 16 * nt + (lane & 15);
     const int px = nn / COUT, co = nn % COUT;
     const float bv = bias[co];
-    const size_t plane_off = (size_t)(co >> 3) * Vout * 8 + (co & 7);
 #pragma unroll
-    for (int i = 0; i < G::MPW; ++i) {
-        const int t = mg * G::MPW + i;
-        const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
-        const int gz = iz0 + tz;
+    for (int pz = 0; pz < 2; ++pz) {
+        size_t uo[UPT];
+        int usrc[UPT];
+        float sk16[UPT][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = 4 * (lane >> 4) + e;
-            const int gy = iy0 + 2 * ty + (m >> 3), gx = ix0 + 8 * tx + (m & 7);
-            if (gz < Di && gy < Hi && gx < Wi) {
+        for (int j = 0; j < UPT; ++j) {
+            const int u = tid + j * 256;
+            const int ox = u % OX;
+            int t = u / OX;
+            const int oy = t % OY; t /= OY;
+            const int ozl = t % BZ, pl = t / BZ;
+            const int gz = 2 * (iz0 + ozl) + pz, gy = 2 * iy0 + oy, gx = 2 * ix0 + ox;
+            const bool ok = u < NUNIT && gz < Do && gy < Ho && gx < Wo;
+            usrc[j] = ok ? (ozl * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + pl * 8 : -1;
+            uo[j] = ok ? ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8 : 0;
+            load8_16<DT>(skip, uo[j], sk16[j]);
+        }
+        __syncthreads();  // input tile (pass 0) / previous pass's staging tile fully consumed
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls) {
-                    const int oz = 2 * gz + (cls >> 1), oy = 2 * gy + (cls & 1), ox = 2 * gx + px;
-                    const size_t o = plane_off + (((size_t)oz * Ho + oy) * Wo + ox) * 8;
-                    St<DT>::store1(y, o, fmaxf(acc[cls][i][e] + bv, 0.0f) + St<DT>::load1(skip, o));
-                }
+        for (int i = 0; i < G::MPW; ++i) {
+            const int t = mg * G::MPW + i;
+            const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * (lane >> 4) + e;
+                const int ly = 2 * ty + (m >> 3), lx = 8 * tx + (m & 7);  // input voxel inside the block tile
+                const int ox = 2 * lx + px;
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+                    otile[(tz * OY + 2 * ly + py) * RP + ox * COUT + (ox >> 3) * 16 + co] =
+                        fmaxf(acc[2 * pz + py][i][e] + bv, 0.0f);
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+            if (usrc[j] < 0) continue;
+            const float* src = otile + usrc[j];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            const float v[8] = {lo.x + sk16[j][0], lo.y + sk16[j][1], lo.z + sk16[j][2], lo.w + sk16[j][3],
+                                hi.x + sk16[j][4], hi.y + sk16[j][5], hi.z + sk16[j][6], hi.w + sk16[j][7]};
+            store8_16<DT>(y, uo[j], v);
         }
     }
 }
