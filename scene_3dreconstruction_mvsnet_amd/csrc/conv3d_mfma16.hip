@@ -88,7 +88,15 @@ __global__ __launch_bounds__(256) void convg16_mfma_kernel(
     void* __restrict__ y,                     // [COUT/8][Do][Ho][Wo][8] 16-bit
     int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
     using G = ConvG16<CIN, COUT, S, BZ, BY, BX>;
-    __shared__ __attribute__((aligned(16))) unsigned short tile[G::TILE_ELEMS];
+    // epilogue staging tile (fp32): the block's BZ x 2BY x 8BX output voxels x COUT channels, rows padded (16 floats per 8
+    // voxels, row pitch = 16 mod 32 floats) so that the accumulator scatter is conflict-free
+    constexpr int OY = 2 * BY, OX = 8 * BX;
+    constexpr int RP0 = OX * COUT + 16 * (OX / 8), RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
+    constexpr int OUT_FLOATS = BZ * OY * RP, NUNIT = BZ * OY * OX * (COUT / 8), UPT = (NUNIT + 255) / 256;
+    constexpr int LDS_BYTES = G::TILE_ELEMS * 2 > OUT_FLOATS * 4 ? G::TILE_ELEMS * 2 : OUT_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned short* tile = reinterpret_cast<unsigned short*>(lds_raw);
+    float* otile = reinterpret_cast<float*>(lds_raw);
     const unsigned short* xs = static_cast<const unsigned short*>(x);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,20 +197,38 @@ __global__ __launch_bounds__(256) void convg16_mfma_kernel(
 #undef MVS_LOAD_A
 #undef MVS_STORE_A
 
+    // epilogue: ReLU(acc + bias) scattered into the LDS tile [oz][oy][ox][co], then every thread owns whole voxels of one C8
+    // plane (8 channels) and stores them 16 bytes at a time, contiguous across the wave (the scalar form stored single
+    // elements: 2- or 4-byte pieces in 16- or 32-byte runs)
     const int n = lane & 15, co = 16 * nt + n;
     const float bv = bias[co];
-    const size_t yplane = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+    __syncthreads();   // the input tile is fully consumed
 #pragma unroll
     for (int i = 0; i < G::MPW; ++i) {
         const int t = mg * G::MPW + i;
         const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
-        const int gz = oz0 + tz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * (lane >> 4) + e;
-            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
-            if (gz < Do && gy < Ho && gx < Wo)
-                St<DT>::store1(y, yplane + (((size_t)gz * Ho + gy) * Wo + gx) * 8, fmaxf(acc[i][e] + bv, 0.0f));
+            const int oy = 2 * ty + (m >> 3), ox = 8 * tx + (m & 7);
+            otile[(tz * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + co] = fmaxf(acc[i][e] + bv, 0.0f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int u = tid + j * 256;
+        const int ox = u % OX;
+        int t = u / OX;
+        const int oy = t % OY; t /= OY;
+        const int ozl = t % BZ, pl = t / BZ;
+        const int gz = oz0 + ozl, gy = oy0 + oy, gx = ox0 + ox;
+        if (u < NUNIT && gz < Do && gy < Ho && gx < Wo) {
+            const float* src = otile + (ozl * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + pl * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            const size_t uo = ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8;
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            store8_16<DT>(y, uo, v);
         }
     }
 }
@@ -1163,7 +1189,15 @@ __global__ __launch_bounds__(256) void convgs_mfma_kernel(
     float* __restrict__ y,                    // [COUT/8][Do][Ho][Wo][8] fp32
     int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
     using G = ConvG16<CIN, COUT, S, BZ, BY, BX>;
-    __shared__ __attribute__((aligned(16))) unsigned short tile[3 * G::TILE_ELEMS];
+    // epilogue staging tile (fp32): the block's BZ x 2BY x 8BX output voxels x COUT channels, rows padded (16 floats per 8
+    // voxels, row pitch = 16 mod 32 floats) so that the accumulator scatter is conflict-free
+    constexpr int OY = 2 * BY, OX = 8 * BX;
+    constexpr int RP0 = OX * COUT + 16 * (OX / 8), RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
+    constexpr int OUT_FLOATS = BZ * OY * RP, NUNIT = BZ * OY * OX * (COUT / 8), UPT = (NUNIT + 255) / 256;
+    constexpr int LDS_BYTES = 3 * G::TILE_ELEMS * 2 > OUT_FLOATS * 4 ? 3 * G::TILE_ELEMS * 2 : OUT_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned short* tile = reinterpret_cast<unsigned short*>(lds_raw);
+    float* otile = reinterpret_cast<float*>(lds_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NT, mg = wave / G::NT;
@@ -1281,20 +1315,38 @@ __global__ __launch_bounds__(256) void convgs_mfma_kernel(
         }
     }
 
+    // epilogue: ReLU(acc + bias) scattered into the LDS tile [oz][oy][ox][co], then every thread owns whole voxels of one C8
+    // plane (8 channels) and stores them 16 bytes at a time, contiguous across the wave (the scalar form stored single
+    // elements: 2- or 4-byte pieces in 16- or 32-byte runs)
     const int n = lane & 15, co = 16 * nt + n;
     const float bv = bias[co];
-    const size_t yplane = (size_t)(co >> 3) * Vout * 8 + (co & 7);
+    __syncthreads();   // the input tile is fully consumed
 #pragma unroll
     for (int i = 0; i < G::MPW; ++i) {
         const int t = mg * G::MPW + i;
         const int tx = t % BX, ty = (t / BX) % BY, tz = t / (BX * BY);
-        const int gz = oz0 + tz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * (lane >> 4) + e;
-            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
-            if (gz < Do && gy < Ho && gx < Wo)
-                y[yplane + (((size_t)gz * Ho + gy) * Wo + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+            const int oy = 2 * ty + (m >> 3), ox = 8 * tx + (m & 7);
+            otile[(tz * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + co] = fmaxf(acc[i][e] + bv, 0.0f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int u = tid + j * 256;
+        const int ox = u % OX;
+        int t = u / OX;
+        const int oy = t % OY; t /= OY;
+        const int ozl = t % BZ, pl = t / BZ;
+        const int gz = oz0 + ozl, gy = oy0 + oy, gx = ox0 + ox;
+        if (u < NUNIT && gz < Do && gy < Ho && gx < Wo) {
+            const float* src = otile + (ozl * OY + oy) * RP + ox * COUT + (ox >> 3) * 16 + pl * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            const size_t uo = ((size_t)pl * Vout + ((size_t)gz * Ho + gy) * Wo + gx) * 8;
+            *reinterpret_cast<f32x4*>(y + uo) = lo;
+            *reinterpret_cast<f32x4*>(y + uo + 4) = hi;
         }
     }
 }
