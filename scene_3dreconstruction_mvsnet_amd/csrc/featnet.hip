@@ -61,7 +61,13 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
     float* __restrict__ y,           // [COUT/8][N][Ho][Wo][8]
     int N, int Hi, int Wi, int Ho, int Wo) {
     using G = FConv<CIN, COUT, KW, S, BY, BX>;
-    __shared__ __attribute__((aligned(16))) float tile[G::TILE_FLOATS];
+    // epilogue staging tile: the block's 2BY x 8BX output pixels x (padded) COUT channels, rows padded (16 floats per 8
+    // pixels, row pitch = 16 mod 32 floats) so that the accumulator scatter is conflict-free
+    constexpr int OY = 2 * BY, OX = 8 * BX, CP = 16 * G::NT;
+    constexpr int RP0 = OX * CP + 16 * (OX / 8), RP = (RP0 % 32 == 16) ? RP0 : RP0 + 16;
+    constexpr int OUT_FLOATS = OY * RP, NPL = (COUT + 7) / 8, NUNIT = OY * OX * NPL, UPT = (NUNIT + 255) / 256;
+    constexpr int LDS_FLOATS = G::TILE_FLOATS > OUT_FLOATS ? G::TILE_FLOATS : OUT_FLOATS;
+    __shared__ __attribute__((aligned(16))) float tile[LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = wave % G::NT, mg = wave / G::NT;
@@ -191,11 +197,12 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
 #undef FN_LOAD_B
 #undef FN_MFMA_CHUNK
 
-    // epilogue: D layout col = lane&15 -> co = 16 nt + col; row m = 4 (lane>>4) + e -> pixel of tile
+    // epilogue: D layout col = lane&15 -> co = 16 nt + col; row m = 4 (lane>>4) + e -> pixel of tile.  bias (+ ReLU) scattered
+    // into the LDS tile [oy][ox][co], then every thread owns whole pixels of one C8 plane (32 B) and stores them 16 bytes at a
+    // time, contiguous across the wave (the scalar form stored 4-byte pieces in 32-byte runs)
     const int col = lane & 15, co = 16 * nt + col;
-    if (co >= COUT) return;
-    const float bv = bias[co];
-    float* yplane = y + ((size_t)(co >> 3) * N + n) * HWo * 8 + (co & 7);
+    const float bv = co < COUT ? bias[co] : 0.0f;
+    __syncthreads();   // the input tile is fully consumed
 #pragma unroll
     for (int i = 0; i < G::MPW; ++i) {
         const int t = mg * G::MPW + i;
@@ -203,26 +210,28 @@ __global__ __launch_bounds__(256) void fconv_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * (lane >> 4) + e;
-            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
-            if (gy < Ho && gx < Wo) {
-                const float v = acc[i][e] + bv;
-                yplane[((size_t)gy * Wo + gx) * 8] = RELU ? fmaxf(v, 0.0f) : v;
-            }
+            const int oy = 2 * ty + (m >> 3), ox = 8 * tx + (m & 7);
+            const float v = acc[i][e] + bv;
+            tile[oy * RP + ox * CP + (ox >> 3) * 16 + co] = RELU ? fmaxf(v, 0.0f) : v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int u = tid + j * 256;
+        const int ox = u % OX;
+        int t = u / OX;
+        const int oy = t % OY, pl = t / OY;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (u < NUNIT && gy < Ho && gx < Wo) {
+            const float* src = tile + oy * RP + ox * CP + (ox >> 3) * 16 + pl * 8;
+            float* dst = y + (((size_t)pl * N + n) * HWo + (size_t)gy * Wo + gx) * 8;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+            *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(src + 4);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// conv0 + conv1 fused (models/mvsnet.py:15-16,27): both run at full resolution with 8 output
-// channels, so as separate kernels they are pure HBM round trips (2 x 52 MB at 5 x 512 x 640).
-// Here a block stages the 12 x 36 RGB halo of its 8 x 32 output tile, evaluates conv0 (27 taps x
-// 8 channels, 216 FMAs per pixel) on the VALU for the 10 x 34 pixels conv1 needs, writes them
-// straight into conv1's LDS A-tile (zero where the pixel lies outside the image: conv1 pads
-// conv0's OUTPUT with zeros), then runs conv1 on the MFMA as fconv_mfma_kernel does.
-// ---------------------------------------------------------------------------------------------
-// FMT: pixel format of `img` -- 0 = fp32 [N][3][H][W] (the reference's tensor); 1 = uint8 [N][3][H][W]; 2 = uint8
-// [N][H][W][3] (as PIL yields a decoded image).  The uint8 forms are divided by 255 here with an IEEE division: the
-// value the reference's loader produces on the host (np.array(img, float32) / 255., datasets/data_io.py:143), bit for bit.
 template <int FMT>
 __global__ __launch_bounds__(256) void fconv01_fused_kernel(
     const void* __restrict__ img_v,  // [N][3][H][W] fp32 / uint8, or [N][H][W][3] uint8
