@@ -363,19 +363,35 @@ __global__ __launch_bounds__(256) void fconv01_fused_kernel(
 #pragma unroll
         for (int i = 0; i < G::MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bq.w, acc[i], 0, 0, 0);
     }
+    // epilogue: bias + ReLU scattered into the LDS tile [oy 8][ox 32][8 channels] (row pitch 272 floats = 16 mod 32), then every
+    // thread owns whole pixels (32 B) and stores them 16 bytes at a time, contiguous across the wave
+    constexpr int ORP = 32 * 8 + 16;
+    static_assert(8 * ORP <= G::TILE_FLOATS, "the staging tile re-uses the input tile");
     const int col = lane & 15;
-    if (col >= 8) return;
-    const float bv = bias[col];
-    float* yplane = y + (size_t)n * HW * 8 + col;
+    const float bv = col < 8 ? bias[col] : 0.0f;
+    __syncthreads();   // the conv0_1 input tile is fully consumed
+    if (col < 8) {
 #pragma unroll
-    for (int i = 0; i < G::MPW; ++i) {
-        const int t = wave * G::MPW + i;
-        const int tx = t % 4, ty = t / 4;
+        for (int i = 0; i < G::MPW; ++i) {
+            const int t = wave * G::MPW + i;
+            const int tx = t % 4, ty = t / 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = 4 * (lane >> 4) + e;
-            const int gy = oy0 + 2 * ty + (m >> 3), gx = ox0 + 8 * tx + (m & 7);
-            if (gy < H && gx < W) yplane[((size_t)gy * W + gx) * 8] = fmaxf(acc[i][e] + bv, 0.0f);
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * (lane >> 4) + e;
+                tile[(2 * ty + (m >> 3)) * ORP + (8 * tx + (m & 7)) * 8 + col] = fmaxf(acc[i][e] + bv, 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    float* yimg = y + (size_t)n * HW * 8;
+    {
+        const int ox = tid & 31, oy = tid >> 5;   // 256 threads = 8 rows x 32 pixels
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (gy < H && gx < W) {
+            const float* src = tile + oy * ORP + ox * 8;
+            float* dst = yimg + ((size_t)gy * W + gx) * 8;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+            *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(src + 4);
         }
     }
 }
