@@ -254,6 +254,11 @@ static bool tile_fills_chip(int Di, int Hi, int Wi, int S, int BZ, int BY, int B
             n = 256;
         return n;
     }();
+    static const int force = [] {   // MVS_DEEP_TILES=1 / 0: always / never (tests, A/B runs)
+        const char* e = getenv("MVS_DEEP_TILES");
+        return e ? atoi(e) : -1;
+    }();
+    if (force >= 0) return force != 0;
     const int Do = (Di - 1) / S + 1, Ho = (Hi - 1) / S + 1, Wo = (Wi - 1) / S + 1;
     const long nb = (long)((Wo + 8 * BX - 1) / (8 * BX)) * ((Ho + 2 * BY - 1) / (2 * BY)) * ((Do + BZ - 1) / BZ);
     return 2 * nb >= 3 * (long)cus;

@@ -442,6 +442,11 @@ def test_16bit_storage_fp32_arithmetic_variant(storage):
     ({"MVS_CONV1Z": "1"}, ("24", "24", "40", "f32")),
     ({"MVS_CONV1Z": "1"}, ("16", "16", "32", "f32")),
     ({"MVS_CONV1Z": "0"}, ("16", "16", "32", "f32")),
+    # z-deep block tiles of the 16-bit tile kernels (conv4 - conv7, conv9: default where they still fill the chip), forced at
+    # shapes with ragged tiles in every direction, and the round-2 tiles forced where the default takes the deep ones
+    ({"MVS_DEEP_TILES": "1"}, ("24", "40", "56", "f16", "bf16")),
+    ({"MVS_DEEP_TILES": "1"}, ("16", "24", "40", "bf16")),
+    ({"MVS_DEEP_TILES": "0"}, ("16", "24", "40", "f16")),
 ])
 def test_full_size_only_code_paths_at_small_shapes(env, shape):
     """Kernels / launch orders that the default selection reaches only at full size, forced at a
