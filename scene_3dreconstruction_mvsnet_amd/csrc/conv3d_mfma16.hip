@@ -270,7 +270,7 @@ static int launch_convg16_dt(int layer, const void* x, void* y, const unsigned s
     switch (layer) {
         case 1: return run_convg16<DT, 8, 16, 2, 2, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
         case 2: return run_convg16<DT, 16, 16, 1, 2, 4, 2>(x, y, bp, bias, Di, Hi, Wi, s);
-        case 3: return run_convg16<DT, 16, 32, 2, 1, 2, 2>(x, y, bp, bias, Di, Hi, Wi, s);
+        case 3: return run_convg16<DT, 16, 32, 2, 4, 1, 1>(x, y, bp, bias, Di, Hi, Wi, s);   // cfg5 sweep: 1x2x2 0.0115, 4x1x1 0.0107 ms
         // conv4 .. conv6: z-deep block tiles (halo planes re-used) wherever they still give every CU a block and a half --
         // round-4 sweep, cfg3 bf16 (1600x1184x256): conv4 1x2x2 -> 4x2x1 0.0574 -> 0.0456 ms, conv5 1x1x1 -> 2x1x1 0.0296 -> 0.0236,
         // conv6 1x1x1 -> 4x1x1 0.0479 -> 0.0243; cfg5 fp16 (640x512x192): conv4 0.0133 -> 0.0118, conv5 / conv6 keep 1x1x1
