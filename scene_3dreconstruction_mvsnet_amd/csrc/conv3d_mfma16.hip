@@ -856,6 +856,11 @@ static int try_convz16(int layer, const void* x, void* y, const unsigned short* 
     // enough columns x 8-plane chunks to fill the chip (cfg5's conv3 -- 12 columns of 48 planes -- measured 0.016 vs
     // 0.012 ms for the tile kernel: short chunks pay the two-step prologue too often)
     if (zm != 1 && ncol * (Do / 8) * 4 < (long)cus * 3) return MVS_OK;
+    // round 4, after the tile kernels got z-deep tiles, the XCD-aware order and staged epilogues: conv3 is faster on the tile
+    // kernel at every bench size (cfg3 0.0433-0.0448 against 0.0456-0.0463 ms, cfg5 0.0108 against 0.0154), conv2 on it at cfg5's
+    // size (0.0178 against 0.0204-0.0214) but not at cfg3's (0.106 against 0.087); conv1 stays here (cfg5 0.0215 / 0.0256, cfg3
+    // 0.113 / 0.148)
+    if (zm != 1 && (layer == 3 || (layer == 2 && ncol * (Do / 8) < (long)cus * 3))) return MVS_OK;
     *taken = true;
     switch (layer) {
         case 1: return run_convz16<DT, 8, 16, 2>(x, y, bp, bias, Di, Hi, Wi, Do, Ho, Wo, cus, s);
