@@ -477,7 +477,10 @@ int launch_tc2_dt(const void* feats_p, const float* rt, const float* dv, void* v
     // 32 / 64 = 1.95 / 1.86 / 1.78 ms): the linear block id then sends slab s of EVERY pixel block to XCD s % 8, so every
     // XCD's L2 streams the whole feature set
     int slab = 40;
-    if (((D + slab - 1) / slab) % 8 == 0) slab += 4;
+    for (const int cand : {40, 44, 36, 32, 28, 24}) {   // the first whose slab count is not a multiple of 8 (D = 320: 36)
+        slab = cand;
+        if (((D + cand - 1) / cand) % 8 != 0) break;
+    }
     constexpr int pix = 256 / (32 / CPT);
     constexpr size_t fes = FDT == MVS_F32 ? 4 : 2;
     // all views' features against the 32 MB of aggregate L2 (MVS_WARP_DEPTH_FASTEST=1 forces the order)
